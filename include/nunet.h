@@ -1,0 +1,225 @@
+/*
+ * nunet.h — C ABI of libnunet.so: the MI355X (gfx950) UNet++ hot path.
+ *
+ * The reference (husheng876/pytorch_nested-unet) has no native interface; its
+ * "plugin API" for this path is the Python surface
+ *     archs.__dict__[arch](num_classes, input_channels, deep_supervision)   trains.py:219-221
+ *     losses.__dict__[loss]()                                               trains.py:213
+ *     iou_score(output, target)                                             trains.py:124,128
+ *     optim.SGD(...).step()                                                 trains.py:229-231,133
+ * Each entry below names the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every entry returns 0 on success, a negative NUNET_E* otherwise;
+ *     nunet_last_error() returns a thread-local message.
+ *   - the caller owns every buffer (PyTorch caching allocator); the library
+ *     allocates nothing on the device. Sizes come from *_bytes() queries.
+ *   - all work is enqueued on the caller's hipStream_t; nothing synchronises.
+ *   - activations are NHWC ("pitch" = elements between consecutive pixels);
+ *     packed conv weights are KRSC: [tap][Cout][Cin] with tap = kh*3+kw.
+ *   - dtype: storage type of activations and packed weights. Accumulation,
+ *     BatchNorm statistics, loss, gradients of parameters are always fp32.
+ */
+#ifndef NUNET_H
+#define NUNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nunet_stream_t; /* hipStream_t */
+
+enum { NUNET_F32 = 0, NUNET_BF16 = 1, NUNET_F16 = 2 };
+enum {
+  NUNET_OK = 0,
+  NUNET_EINVAL = -1,  /* bad argument / unsupported shape */
+  NUNET_ELAUNCH = -2, /* HIP launch error */
+  NUNET_ENODEV = -3   /* no gfx950 device / code object */
+};
+
+int nunet_version(void);
+const char* nunet_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* 3x3 convolution, pad 1, stride 1 (nn.Conv2d(ci,co,3,padding=1),           */
+/* reference finished/archs1.py:18,20) and its two gradients.                */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int32_t dtype;
+  int32_t N, H, W;
+  /* input = channel concat of up to two NHWC sources (zero-copy torch.cat,
+   * reference finished/archs1.py:116-131) */
+  const void* src0; int32_t C0, P0;
+  const void* src1; int32_t C1, P1; /* C1 = 0: unused */
+  const void* wpack;                /* [9][Cout][Cin], dtype; Cin = C0+C1 */
+  const float* bias;                /* [Cout] fp32 or NULL */
+  /* output = channel split into up to two NHWC destinations */
+  void* dst0; int32_t D0, Q0;
+  void* dst1; int32_t D1, Q1;       /* D1 = 0: unused */
+  int32_t acc_slot_w;               /* width (channels) of one dst0 slot, 0 = D0 */
+  uint32_t acc0_mask;               /* bit k: dst0 slot k accumulates (+=) */
+  int32_t acc1;                     /* dst1 accumulates */
+  float* stats;                     /* [2][Cout] fp32: += sum(y-b), sum((y-b)^2) or NULL */
+} nunet_conv_desc;
+
+/* y = conv(cat(src0,src1)) + bias. Also used as dgrad with the flipped,
+ * transposed pack (see nunet_pack_weights). */
+int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s);
+
+typedef struct {
+  int32_t dtype;
+  int32_t N, H, W;
+  const void* src0; int32_t C0, P0; /* forward input (concat) */
+  const void* src1; int32_t C1, P1;
+  const void* dy;   int32_t Cout, PY; /* grad wrt raw conv output */
+  float* dw;                        /* [9][Cout][Cin] fp32, atomically accumulated */
+} nunet_wgrad_desc;
+
+/* dw[tap][co][ci] += sum_p dy[p][co] * x[p+tap][ci] */
+int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s);
+
+/* OIHW fp32 -> packed KRSC `dtype`:
+ *   wf[tap][co][ci]      (forward;  ci padded with zeros up to cin_pad)
+ *   wd[8-tap][ci][co]    (dgrad: flipped taps, transposed; may be NULL) */
+int nunet_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t cin_pad,
+                       int32_t dtype, void* wf, void* wd, nunet_stream_t s);
+/* native fp32 dw[tap][co][cin_pad] -> OIHW grad (assign or +=) */
+int nunet_unpack_wgrad(const float* dw, int32_t cout, int32_t cin, int32_t cin_pad,
+                       float* g_oihw, int32_t accumulate, nunet_stream_t s);
+
+/* ------------------------------------------------------------------------ */
+/* BatchNorm2d (+ReLU) — nn.BatchNorm2d / nn.ReLU at finished/archs1.py:17-21 */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int32_t dtype;
+  int32_t N, H, W, C;
+  const void* y; int32_t PY;        /* raw conv output */
+  const float* conv_bias;           /* [C]: stats are accumulated about the bias */
+  const float* stats;               /* [2][C] sums from nunet_conv3x3_fwd (training) */
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* save_mean_invstd;          /* [2][C] out (training) */
+  int32_t training;
+  float momentum, eps;
+  void* a; int32_t PA;              /* relu(bn(y)) */
+  void* pooled; int32_t PP;         /* optional fused MaxPool2d(2,2) of a, or NULL */
+} nunet_bn_fwd_desc;
+int nunet_bn_relu_fwd(const nunet_bn_fwd_desc* d, nunet_stream_t s);
+
+typedef struct {
+  int32_t dtype;
+  int32_t N, H, W, C;
+  const void* da; int32_t PDA;      /* grad wrt relu(bn(y)) */
+  const void* y;  int32_t PY;
+  const float* mean_invstd;         /* [2][C] */
+  const float* gamma; const float* beta;
+  float* sums;                      /* [2][C] scratch, zeroed by caller: sum dz, sum dz*xhat */
+  float* dgamma; float* dbeta;      /* [C] += */
+  float* dbias;                     /* [C] += sum dy (conv bias grad) */
+  void* dy; int32_t PDY;            /* grad wrt raw conv output */
+} nunet_bn_bwd_desc;
+int nunet_bn_relu_bwd_reduce(const nunet_bn_bwd_desc* d, nunet_stream_t s);
+int nunet_bn_relu_bwd_apply(const nunet_bn_bwd_desc* d, nunet_stream_t s);
+
+/* ------------------------------------------------------------------------ */
+/* MaxPool2d(2,2) (archs1.py:82) and Upsample(x2, bilinear, align_corners)   */
+/* (archs1.py:83)                                                            */
+/* ------------------------------------------------------------------------ */
+int nunet_maxpool2x2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                         const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s);
+/* dx (+)= route(dy) to the first max in PyTorch scan order */
+int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                         const void* x, int32_t PX, const void* dy, int32_t PDY,
+                         void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s);
+/* H, W are the INPUT (low-res) extents; output is 2H x 2W */
+int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                         const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s);
+int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                         const void* dy, int32_t PDY, void* dx, int32_t PDX,
+                         int32_t accumulate, nunet_stream_t s);
+
+/* ------------------------------------------------------------------------ */
+/* 1x1 heads: nn.Conv2d(32, num_classes, 1) at archs1.py:105-111,133-143     */
+/* ------------------------------------------------------------------------ */
+/* logits NCHW fp32 [N][K][H][W] */
+int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K,
+                   const void* x, int32_t PX, const float* w, const float* b,
+                   float* logits, nunet_stream_t s);
+int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K,
+                   const void* x, int32_t PX, const float* w, const float* dlogits,
+                   void* dx, int32_t PDX, int32_t accumulate,
+                   float* dw, float* db, nunet_stream_t s);
+
+/* ------------------------------------------------------------------------ */
+/* BCEDiceLoss (losses.py:103-117), iou_score (metrics.py:6-18)              */
+/* ------------------------------------------------------------------------ */
+/* sums: [N][3] (sum p*t, sum p, sum t) + [1] (sum bce), zeroed here. loss: [1]. */
+size_t nunet_bce_dice_ws_bytes(int32_t N);
+int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int64_t per_sample,
+                       float* ws, float* loss, nunet_stream_t s);
+/* dlogits = gscale[0] * dloss/dlogits */
+int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per_sample,
+                       const float* ws, const float* gscale, float* dlogits, nunet_stream_t s);
+/* counts[0] += |A&B|, counts[1] += |A|B|, A = logits>0, B = target>0.5 */
+int nunet_iou_counts(const float* logits, const float* target, int64_t n,
+                     unsigned long long* counts, nunet_stream_t s);
+
+/* ------------------------------------------------------------------------ */
+/* optim.SGD.step as configured at trains.py:229-231                         */
+/* ------------------------------------------------------------------------ */
+/* lr is read from device memory so a captured graph can be re-used across
+ * scheduler steps. first != 0: momentum buffer := grad (torch semantics). */
+int nunet_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* lr_dev,
+                   float momentum, float weight_decay, int32_t nesterov, int32_t first,
+                   float grad_scale, nunet_stream_t s);
+
+/* ------------------------------------------------------------------------ */
+/* layout helpers                                                            */
+/* ------------------------------------------------------------------------ */
+/* NCHW fp32 -> NHWC dtype with channel padding (zeros) up to cpad */
+int nunet_nchw_to_nhwc(const float* x, int32_t N, int32_t C, int32_t H, int32_t W,
+                       int32_t dtype, void* y, int32_t cpad, nunet_stream_t s);
+
+/* ------------------------------------------------------------------------ */
+/* Whole-network plan: NestedUNet.forward (archs1.py:113-143) + its backward */
+/* ------------------------------------------------------------------------ */
+typedef struct nunet_plan nunet_plan;
+typedef struct {
+  int32_t N, H, W;
+  int32_t input_channels, num_classes, deep_supervision;
+  int32_t dtype;
+  int32_t unet; /* 0: NestedUNet, 1: plain UNet (archs1.py:35-71) */
+} nunet_plan_cfg;
+
+nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg);
+void nunet_plan_destroy(nunet_plan* p);
+size_t nunet_plan_arena_bytes(const nunet_plan* p);
+/* number of fp32 parameters / BN running-stat floats / BN layers, in
+ * reference state_dict order */
+int64_t nunet_plan_param_count(const nunet_plan* p);
+int64_t nunet_plan_bnbuf_count(const nunet_plan* p);
+int32_t nunet_plan_bn_layers(const nunet_plan* p);
+int32_t nunet_plan_num_heads(const nunet_plan* p);
+
+/* params: flat fp32, reference parameters() order (OIHW conv weights).
+ * bnbuf:  flat fp32 [running_mean, running_var] per BN in state_dict order.
+ * nbt:    int64 per BN layer.
+ * input:  NCHW fp32. logits: [heads][N][K][H][W] fp32. */
+int nunet_plan_forward(nunet_plan* p, const float* params, float* bnbuf, int64_t* nbt,
+                       const float* input, void* arena, float* logits, int32_t training,
+                       nunet_stream_t s);
+/* grads: flat fp32 in params order. accumulate: += instead of assign. */
+int nunet_plan_backward(nunet_plan* p, const float* params, const float* dlogits, void* arena,
+                        float* grads, int32_t accumulate, nunet_stream_t s);
+/* debug/test access to an intermediate: name like "x0_0", "x2_1" (block
+ * outputs, NHWC). Returns byte offset into arena; fills pitch/channels. */
+int64_t nunet_plan_feature(const nunet_plan* p, int32_t i, int32_t j, int32_t* pitch,
+                           int32_t* channels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUNET_H */

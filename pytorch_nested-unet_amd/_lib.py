@@ -1,0 +1,157 @@
+"""ctypes binding of libnunet.so (include/nunet.h). No torch types cross the ABI:
+only raw device pointers, sizes and the hipStream_t of torch's current stream.
+
+The product path fails loudly when the HIP extension is missing: there is no
+CPU or eager-PyTorch fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnunet.so")
+
+F32, BF16, F16 = 0, 1, 2
+DTYPES = {"fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F16, "float16": F16,
+          torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+
+_vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", _i32), ("N", _i32), ("H", _i32), ("W", _i32),
+                ("src0", _vp), ("C0", _i32), ("P0", _i32),
+                ("src1", _vp), ("C1", _i32), ("P1", _i32),
+                ("wpack", _vp), ("bias", _vp),
+                ("dst0", _vp), ("D0", _i32), ("Q0", _i32),
+                ("dst1", _vp), ("D1", _i32), ("Q1", _i32),
+                ("acc_slot_w", _i32), ("acc0_mask", _u32), ("acc1", _i32),
+                ("stats", _vp)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("dtype", _i32), ("N", _i32), ("H", _i32), ("W", _i32),
+                ("src0", _vp), ("C0", _i32), ("P0", _i32),
+                ("src1", _vp), ("C1", _i32), ("P1", _i32),
+                ("dy", _vp), ("Cout", _i32), ("PY", _i32),
+                ("dw", _vp)]
+
+
+class BnFwdDesc(C.Structure):
+    _fields_ = [("dtype", _i32), ("N", _i32), ("H", _i32), ("W", _i32), ("C", _i32),
+                ("y", _vp), ("PY", _i32),
+                ("conv_bias", _vp), ("stats", _vp), ("gamma", _vp), ("beta", _vp),
+                ("running_mean", _vp), ("running_var", _vp), ("num_batches_tracked", _vp),
+                ("save_mean_invstd", _vp),
+                ("training", _i32), ("momentum", _f32), ("eps", _f32),
+                ("a", _vp), ("PA", _i32), ("pooled", _vp), ("PP", _i32)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [("dtype", _i32), ("N", _i32), ("H", _i32), ("W", _i32), ("C", _i32),
+                ("da", _vp), ("PDA", _i32), ("y", _vp), ("PY", _i32),
+                ("mean_invstd", _vp), ("gamma", _vp), ("beta", _vp),
+                ("sums", _vp), ("dgamma", _vp), ("dbeta", _vp), ("dbias", _vp),
+                ("dy", _vp), ("PDY", _i32)]
+
+
+class PlanCfg(C.Structure):
+    _fields_ = [("N", _i32), ("H", _i32), ("W", _i32),
+                ("input_channels", _i32), ("num_classes", _i32), ("deep_supervision", _i32),
+                ("dtype", _i32), ("unet", _i32)]
+
+
+# every symbol include/nunet.h declares: name -> (restype, argtypes)
+_SIG = {
+    "nunet_version": (_i32, []),
+    "nunet_last_error": (C.c_char_p, []),
+    "nunet_conv3x3_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "nunet_conv3x3_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "nunet_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "nunet_unpack_wgrad": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "nunet_bn_relu_fwd": (_i32, [C.POINTER(BnFwdDesc), _vp]),
+    "nunet_bn_relu_bwd_reduce": (_i32, [C.POINTER(BnBwdDesc), _vp]),
+    "nunet_bn_relu_bwd_apply": (_i32, [C.POINTER(BnBwdDesc), _vp]),
+    "nunet_maxpool2x2_fwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp]),
+    "nunet_maxpool2x2_bwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "nunet_upsample2x_fwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp]),
+    "nunet_upsample2x_bwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _i32, _vp]),
+    "nunet_head_fwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "nunet_head_bwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "nunet_bce_dice_ws_bytes": (C.c_size_t, [_i32]),
+    "nunet_bce_dice_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "nunet_bce_dice_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "nunet_iou_counts": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "nunet_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _i32, _f32, _vp]),
+    "nunet_nchw_to_nhwc": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "nunet_plan_create": (_vp, [C.POINTER(PlanCfg)]),
+    "nunet_plan_destroy": (None, [_vp]),
+    "nunet_plan_arena_bytes": (C.c_size_t, [_vp]),
+    "nunet_plan_param_count": (_i64, [_vp]),
+    "nunet_plan_bnbuf_count": (_i64, [_vp]),
+    "nunet_plan_bn_layers": (_i32, [_vp]),
+    "nunet_plan_num_heads": (_i32, [_vp]),
+    "nunet_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "nunet_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "nunet_plan_feature": (_i64, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+}
+
+_lib = None
+
+
+class NunetError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libnunet.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise NunetError("building libnunet.so failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NunetError("libnunet.so is missing at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU/PyTorch fallback for the HIP path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIG.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise NunetError("%s failed (%d): %s" % (what or "libnunet call", rc, lib().nunet_last_error().decode()))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, byte_offset=0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + byte_offset)
+
+
+def require_gpu_tensor(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise NunetError("%s must live on the MI355X (got %s); this package has no CPU path" % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise NunetError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise NunetError("%s must be contiguous" % name)

@@ -1,0 +1,111 @@
+// common.h — shared device/host helpers for libnunet (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <type_traits>
+
+#include "../../include/nunet.h"
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+void nunet_set_error(const char* fmt, ...);
+int nunet_check_launch(const char* what);
+
+#define NUNET_REQUIRE(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      nunet_set_error(__VA_ARGS__);         \
+      return NUNET_EINVAL;                  \
+    }                                       \
+  } while (0)
+
+static inline int dtype_size(int dt) { return dt == NUNET_F32 ? 4 : 2; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------
+// storage-type traits: EPV = elements per 16-byte vector
+// ---------------------------------------------------------------------------
+template <typename T> struct Tr;
+template <> struct Tr<float> {
+  static constexpr int EPV = 4;
+  static constexpr int DT = NUNET_F32;
+};
+template <> struct Tr<bf16_t> {
+  static constexpr int EPV = 8;
+  static constexpr int DT = NUNET_BF16;
+};
+template <> struct Tr<f16_t> {
+  static constexpr int EPV = 8;
+  static constexpr int DT = NUNET_F16;
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// 16-byte vector of T with element access as float
+template <typename T> struct Vec16 {
+  u32x4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    if constexpr (std::is_same<T, float>::value) {
+      return __builtin_bit_cast(float, raw[i]);
+    } else {
+      uint32_t w = raw[i >> 1];
+      uint16_t hv = (i & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffff);
+      return (float)__builtin_bit_cast(T, hv);
+    }
+  }
+  __device__ __forceinline__ void set(int i, float v) {
+    if constexpr (std::is_same<T, float>::value) {
+      raw[i] = __builtin_bit_cast(uint32_t, v);
+    } else {
+      uint16_t hv = __builtin_bit_cast(uint16_t, (T)v);
+      uint32_t w = raw[i >> 1];
+      w = (i & 1) ? ((w & 0x0000ffffu) | ((uint32_t)hv << 16)) : ((w & 0xffff0000u) | hv);
+      raw[i >> 1] = w;
+    }
+  }
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+  Vec16<T> v;
+  v.raw = *reinterpret_cast<const u32x4*>(p);
+  return v;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<u32x4*>(p) = v.raw;
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+  Vec16<T> v;
+  v.raw = u32x4{0u, 0u, 0u, 0u};
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// dispatch a templated launcher on dtype
+#define NUNET_DISPATCH(dt, FN, ...)                                   \
+  ((dt) == NUNET_F32    ? FN<float>(__VA_ARGS__)                      \
+   : (dt) == NUNET_BF16 ? FN<bf16_t>(__VA_ARGS__)                     \
+   : (dt) == NUNET_F16  ? FN<f16_t>(__VA_ARGS__)                      \
+                        : (nunet_set_error("bad dtype %d", (int)(dt)), NUNET_EINVAL))

@@ -1,0 +1,702 @@
+// elementwise.hip — the HBM-bound kernels of the UNet++ path (NHWC, 16 B/lane):
+//   BatchNorm2d(+ReLU)(+MaxPool2d) forward, BatchNorm/ReLU backward,
+//   MaxPool2d(2,2) fwd/bwd, bilinear x2 align_corners upsample fwd/bwd,
+//   1x1 heads fwd/bwd, BCEDiceLoss fwd/bwd, IoU counts, SGD, layout helpers.
+// Reference arithmetic: finished/archs1.py:17-21,82-83,105-111; losses.py:103-117;
+// metrics.py:6-18; trains.py:229-231.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+void nunet_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int nunet_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    nunet_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return NUNET_ELAUNCH;
+  }
+  return NUNET_OK;
+}
+extern "C" const char* nunet_last_error(void) { return g_err; }
+extern "C" int nunet_version(void) { return 100; }
+
+static inline int grid_for(int64_t items, int block, int cap = 256 * 16) {
+  int64_t g = ceil_div64(items, block);
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// layout: NCHW fp32 -> NHWC T with zero channel padding
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, int H, int W, T* __restrict__ y, int cpad) {
+  const int64_t total = (int64_t)N * H * W * cpad;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad);
+    const int64_t pix = i / cpad;
+    const int64_t hw = (int64_t)H * W;
+    const int n = (int)(pix / hw);
+    const int64_t rem = pix - n * hw;
+    y[i] = (c < C) ? from_f32<T>(x[((int64_t)n * C + c) * hw + rem]) : from_f32<T>(0.f);
+  }
+}
+template <typename T> static int launch_nchw_to_nhwc(const float* x, int N, int C, int H, int W, void* y, int cpad, hipStream_t st) {
+  const int64_t total = (int64_t)N * H * W * cpad;
+  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, x, N, C, H, W, (T*)y, cpad);
+  return nunet_check_launch("nchw_to_nhwc");
+}
+extern "C" int nunet_nchw_to_nhwc(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t dtype, void* y, int32_t cpad, nunet_stream_t s) {
+  NUNET_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && cpad >= C, "nchw_to_nhwc: bad args");
+  return NUNET_DISPATCH(dtype, launch_nchw_to_nhwc, x, N, C, H, W, y, cpad, (hipStream_t)s);
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm (+ReLU) (+2x2 max-pool) forward
+// ---------------------------------------------------------------------------
+struct BnFwdP {
+  const void* y; int PY;
+  const float* conv_bias; const float* stats; const float* gamma; const float* beta;
+  float* rm; float* rv; int64_t* nbt; float* save;
+  int training; float momentum, eps;
+  void* a; int PA; void* pooled; int PP;
+  int N, H, W, C;
+};
+
+__device__ __forceinline__ void bn_channel_coeffs(const BnFwdP& p, int c, float M, float& mean, float& invstd, float& var) {
+  if (p.training) {
+    const float m0 = p.stats[c] / M;
+    var = fmaxf(p.stats[p.C + c] / M - m0 * m0, 0.f);
+    mean = m0 + (p.conv_bias ? p.conv_bias[c] : 0.f);
+  } else {
+    mean = p.rm[c];
+    var = p.rv[c];
+  }
+  invstd = 1.0f / sqrtf(var + p.eps);
+}
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int G = p.C / EPV;  // channel groups; 256 % G == 0
+  const int cg = threadIdx.x % G;
+  const float M = (float)p.N * p.H * p.W;
+  float sc[EPV], sh[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    const int c = cg * EPV + e;
+    float mean, invstd, var;
+    bn_channel_coeffs(p, c, M, mean, invstd, var);
+    sc[e] = p.gamma[c] * invstd;
+    sh[e] = p.beta[c] - mean * sc[e];
+  }
+  if (blockIdx.x == 0 && p.training) {
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+      float mean, invstd, var;
+      bn_channel_coeffs(p, c, M, mean, invstd, var);
+      p.save[c] = mean;
+      p.save[p.C + c] = invstd;
+      if (p.rm) {
+        const float unb = M > 1.f ? var * (M / (M - 1.f)) : var;
+        p.rm[c] = (1.f - p.momentum) * p.rm[c] + p.momentum * mean;
+        p.rv[c] = (1.f - p.momentum) * p.rv[c] + p.momentum * unb;
+      }
+    }
+    if (threadIdx.x == 0 && p.nbt) *p.nbt += 1;
+  }
+  const int ppb = blockDim.x / G;  // pixels (or quads) per block iteration
+  const int pl = threadIdx.x / G;
+  if constexpr (!POOL) {
+    const int64_t npix = (int64_t)p.N * p.H * p.W;
+    for (int64_t pix = (int64_t)blockIdx.x * ppb + pl; pix < npix; pix += (int64_t)gridDim.x * ppb) {
+      Vec16<T> v = ld16((const T*)p.y + pix * p.PY + cg * EPV);
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o.set(e, fmaxf(v.get(e) * sc[e] + sh[e], 0.f));
+      st16((T*)p.a + pix * p.PA + cg * EPV, o);
+    }
+  } else {
+    const int H2 = p.H / 2, W2 = p.W / 2;
+    const int64_t nq = (int64_t)p.N * H2 * W2;
+    for (int64_t q = (int64_t)blockIdx.x * ppb + pl; q < nq; q += (int64_t)gridDim.x * ppb) {
+      const int qx = (int)(q % W2);
+      const int64_t t = q / W2;
+      const int qy = (int)(t % H2);
+      const int n = (int)(t / H2);
+      const int64_t p00 = ((int64_t)n * p.H + 2 * qy) * p.W + 2 * qx;
+      float mx[EPV];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t pix = p00 + (k >> 1) * p.W + (k & 1);
+        Vec16<T> v = ld16((const T*)p.y + pix * p.PY + cg * EPV);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const float a = fmaxf(v.get(e) * sc[e] + sh[e], 0.f);
+          o.set(e, a);
+          const float ar = o.get(e);  // rounded value, as a later pool would see it
+          mx[e] = (k == 0) ? ar : fmaxf(mx[e], ar);
+        }
+        st16((T*)p.a + pix * p.PA + cg * EPV, o);
+      }
+      Vec16<T> po;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) po.set(e, mx[e]);
+      st16((T*)p.pooled + q * p.PP + cg * EPV, po);
+    }
+  }
+}
+
+template <typename T> static int launch_bn_fwd(const nunet_bn_fwd_desc* d, hipStream_t st) {
+  BnFwdP p;
+  p.y = d->y; p.PY = d->PY; p.conv_bias = d->conv_bias; p.stats = d->stats; p.gamma = d->gamma; p.beta = d->beta;
+  p.rm = d->running_mean; p.rv = d->running_var; p.nbt = d->num_batches_tracked; p.save = d->save_mean_invstd;
+  p.training = d->training; p.momentum = d->momentum; p.eps = d->eps;
+  p.a = d->a; p.PA = d->PA; p.pooled = d->pooled; p.PP = d->PP;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C;
+  const int G = d->C / Tr<T>::EPV;
+  const int ppb = 256 / G;
+  if (d->pooled) {
+    const int64_t nq = (int64_t)d->N * (d->H / 2) * (d->W / 2);
+    hipLaunchKernelGGL((bn_relu_fwd_kernel<T, true>), dim3(grid_for(nq, ppb)), dim3(256), 0, st, p);
+  } else {
+    const int64_t np = (int64_t)d->N * d->H * d->W;
+    hipLaunchKernelGGL((bn_relu_fwd_kernel<T, false>), dim3(grid_for(np, ppb)), dim3(256), 0, st, p);
+  }
+  return nunet_check_launch("bn_relu_fwd");
+}
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+extern "C" int nunet_bn_relu_fwd(const nunet_bn_fwd_desc* d, nunet_stream_t s) {
+  NUNET_REQUIRE(d && d->y && d->a && d->gamma && d->beta, "bn_relu_fwd: null pointer");
+  const int epv = 16 / dtype_size(d->dtype);
+  NUNET_REQUIRE(pow2(d->C) && d->C >= epv && d->C / epv <= 256, "bn_relu_fwd: C=%d must be a power of two in [%d, %d]", d->C, epv, 256 * epv);
+  NUNET_REQUIRE(d->PY % epv == 0 && d->PA % epv == 0 && (!d->pooled || d->PP % epv == 0), "bn_relu_fwd: pitch alignment");
+  NUNET_REQUIRE(!d->pooled || (d->H % 2 == 0 && d->W % 2 == 0), "bn_relu_fwd: fused pool needs even H, W");
+  if (d->training) NUNET_REQUIRE(d->stats && d->save_mean_invstd, "bn_relu_fwd: training needs stats and save buffers");
+  else NUNET_REQUIRE(d->running_mean && d->running_var, "bn_relu_fwd: eval needs running stats");
+  return NUNET_DISPATCH(d->dtype, launch_bn_fwd, d, (hipStream_t)s);
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm (+ReLU) backward: reduce pass and apply pass
+// ---------------------------------------------------------------------------
+struct BnBwdP {
+  const void* da; int PDA; const void* y; int PY;
+  const float* mi; const float* gamma; const float* beta;
+  float* sums; float* dgamma; float* dbeta; float* dbias;
+  void* dy; int PDY;
+  int N, H, W, C;
+};
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
+  constexpr int EPV = Tr<T>::EPV;
+  __shared__ float s_acc[2 * 512 * 4];  // [2][C] (C <= 2048 for EPV 8; asserted on host: C <= 2048)
+  const int G = p.C / EPV;
+  const int cg = threadIdx.x % G;
+  const int ppb = blockDim.x / G, pl = threadIdx.x / G;
+  const float M = (float)p.N * p.H * p.W;
+  float sc[EPV], sh[EPV], mean[EPV], istd[EPV], k1[EPV], k2[EPV], gi[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    const int c = cg * EPV + e;
+    mean[e] = p.mi[c];
+    istd[e] = p.mi[p.C + c];
+    sc[e] = p.gamma[c] * istd[e];
+    sh[e] = p.beta[c] - mean[e] * sc[e];
+    if constexpr (APPLY) {
+      k1[e] = p.sums[c] / M;
+      k2[e] = p.sums[p.C + c] / M;
+      gi[e] = sc[e];
+    }
+  }
+  for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) s_acc[c] = 0.f;
+  __syncthreads();
+  float a1[EPV], a2[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  const int64_t npix = (int64_t)p.N * p.H * p.W;
+  for (int64_t pix = (int64_t)blockIdx.x * ppb + pl; pix < npix; pix += (int64_t)gridDim.x * ppb) {
+    const Vec16<T> vy = ld16((const T*)p.y + pix * p.PY + cg * EPV);
+    const Vec16<T> vd = ld16((const T*)p.da + pix * p.PDA + cg * EPV);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float yv = vy.get(e);
+      const float act = yv * sc[e] + sh[e];
+      const float dz = act > 0.f ? vd.get(e) : 0.f;
+      const float xh = (yv - mean[e]) * istd[e];
+      if constexpr (APPLY) {
+        const float dyv = gi[e] * (dz - k1[e] - xh * k2[e]);
+        o.set(e, dyv);
+        a1[e] += o.get(e);
+      } else {
+        a1[e] += dz;
+        a2[e] += dz * xh;
+      }
+    }
+    if constexpr (APPLY) st16((T*)p.dy + pix * p.PDY + cg * EPV, o);
+  }
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    atomicAdd(&s_acc[cg * EPV + e], a1[e]);
+    if constexpr (!APPLY) atomicAdd(&s_acc[p.C + cg * EPV + e], a2[e]);
+  }
+  __syncthreads();
+  if constexpr (APPLY) {
+    if (p.dbias)
+      for (int c = threadIdx.x; c < p.C; c += blockDim.x) atomicAdd(&p.dbias[c], s_acc[c]);
+    if (blockIdx.x == 0) {
+      for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        if (p.dbeta) p.dbeta[c] += p.sums[c];
+        if (p.dgamma) p.dgamma[c] += p.sums[p.C + c];
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) atomicAdd(&p.sums[c], s_acc[c]);
+  }
+}
+
+template <typename T, bool APPLY> static int launch_bn_bwd_t(const nunet_bn_bwd_desc* d, hipStream_t st) {
+  BnBwdP p;
+  p.da = d->da; p.PDA = d->PDA; p.y = d->y; p.PY = d->PY; p.mi = d->mean_invstd; p.gamma = d->gamma; p.beta = d->beta;
+  p.sums = d->sums; p.dgamma = d->dgamma; p.dbeta = d->dbeta; p.dbias = d->dbias; p.dy = d->dy; p.PDY = d->PDY;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C;
+  const int G = d->C / Tr<T>::EPV;
+  const int64_t np = (int64_t)d->N * d->H * d->W;
+  // fewer, fatter blocks: each block ends with 2C global atomics
+  hipLaunchKernelGGL((bn_relu_bwd_kernel<T, APPLY>), dim3(grid_for(np, (256 / G) * 8, 1024)), dim3(256), 0, st, p);
+  return nunet_check_launch(APPLY ? "bn_relu_bwd_apply" : "bn_relu_bwd_reduce");
+}
+template <typename T> static int launch_bn_bwd_reduce(const nunet_bn_bwd_desc* d, hipStream_t st) { return launch_bn_bwd_t<T, false>(d, st); }
+template <typename T> static int launch_bn_bwd_apply(const nunet_bn_bwd_desc* d, hipStream_t st) { return launch_bn_bwd_t<T, true>(d, st); }
+
+static int bn_bwd_check(const nunet_bn_bwd_desc* d, bool apply) {
+  NUNET_REQUIRE(d && d->da && d->y && d->mean_invstd && d->gamma && d->beta && d->sums, "bn_relu_bwd: null pointer");
+  const int epv = 16 / dtype_size(d->dtype);
+  NUNET_REQUIRE(pow2(d->C) && d->C >= epv && d->C / epv <= 256 && d->C <= 2048, "bn_relu_bwd: C=%d unsupported", d->C);
+  NUNET_REQUIRE(d->PY % epv == 0 && d->PDA % epv == 0, "bn_relu_bwd: pitch alignment");
+  if (apply) NUNET_REQUIRE(d->dy && d->PDY % epv == 0, "bn_relu_bwd_apply: dy");
+  return NUNET_OK;
+}
+extern "C" int nunet_bn_relu_bwd_reduce(const nunet_bn_bwd_desc* d, nunet_stream_t s) {
+  int rc = bn_bwd_check(d, false);
+  if (rc) return rc;
+  return NUNET_DISPATCH(d->dtype, launch_bn_bwd_reduce, d, (hipStream_t)s);
+}
+extern "C" int nunet_bn_relu_bwd_apply(const nunet_bn_bwd_desc* d, nunet_stream_t s) {
+  int rc = bn_bwd_check(d, true);
+  if (rc) return rc;
+  return NUNET_DISPATCH(d->dtype, launch_bn_bwd_apply, d, (hipStream_t)s);
+}
+
+// ---------------------------------------------------------------------------
+// MaxPool2d(2,2)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int PX, T* __restrict__ y, int PY, int N, int H, int W, int C) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int G = C / EPV, H2 = H / 2, W2 = W / 2;
+  const int64_t total = (int64_t)N * H2 * W2 * G;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    const int64_t q = i / G;
+    const int qx = (int)(q % W2);
+    const int64_t t = q / W2;
+    const int qy = (int)(t % H2), n = (int)(t / H2);
+    const int64_t p00 = ((int64_t)n * H + 2 * qy) * W + 2 * qx;
+    float mx[EPV];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Vec16<T> v = ld16(x + (p00 + (k >> 1) * W + (k & 1)) * PX + cg * EPV);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) mx[e] = k == 0 ? v.get(e) : fmaxf(mx[e], v.get(e));
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) o.set(e, mx[e]);
+    st16(y + q * PY + cg * EPV, o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int PX, const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int G = C / EPV, H2 = H / 2, W2 = W / 2;
+  const int64_t total = (int64_t)N * H2 * W2 * G;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    const int64_t q = i / G;
+    const int qx = (int)(q % W2);
+    const int64_t t = q / W2;
+    const int qy = (int)(t % H2), n = (int)(t / H2);
+    const int64_t p00 = ((int64_t)n * H + 2 * qy) * W + 2 * qx;
+    Vec16<T> v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ld16(x + (p00 + (k >> 1) * W + (k & 1)) * PX + cg * EPV);
+    const Vec16<T> g = ld16(dy + q * PDY + cg * EPV);
+    int am[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      float m = v[0].get(e);
+      int a = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float f = v[k].get(e);
+        if (f > m) { m = f; a = k; }  // first maximum wins (PyTorch scan order)
+      }
+      am[e] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T* q4 = dx + (p00 + (k >> 1) * W + (k & 1)) * PDX + cg * EPV;
+      Vec16<T> o = accumulate ? ld16(q4) : zero16<T>();
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const float base = accumulate ? o.get(e) : 0.f;
+        o.set(e, am[e] == k ? base + g.get(e) : base);
+      }
+      st16(q4, o);
+    }
+  }
+}
+template <typename T> static int launch_maxpool_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
+  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C);
+  return nunet_check_launch("maxpool_fwd");
+}
+template <typename T> static int launch_maxpool_bwd(int N, int H, int W, int C, const void* x, int PX, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
+  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C);
+  return nunet_check_launch("maxpool_bwd");
+}
+static int ew_check(const char* what, int dtype, int N, int H, int W, int C, int p0, int p1) {
+  const int epv = 16 / dtype_size(dtype);
+  NUNET_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % epv == 0, "%s: bad shape N=%d H=%d W=%d C=%d", what, N, H, W, C);
+  NUNET_REQUIRE(p0 % epv == 0 && p1 % epv == 0 && p0 >= C && p1 >= C, "%s: pitch", what);
+  return NUNET_OK;
+}
+extern "C" int nunet_maxpool2x2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s) {
+  int rc = ew_check("maxpool_fwd", dtype, N, H, W, C, PX, PY);
+  if (rc) return rc;
+  NUNET_REQUIRE(x && y && H % 2 == 0 && W % 2 == 0, "maxpool_fwd: needs even H, W");
+  return NUNET_DISPATCH(dtype, launch_maxpool_fwd, N, H, W, C, x, PX, y, PY, (hipStream_t)s);
+}
+extern "C" int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
+  int rc = ew_check("maxpool_bwd", dtype, N, H, W, C, PX, PDX);
+  if (rc) return rc;
+  NUNET_REQUIRE(x && dy && dx && H % 2 == 0 && W % 2 == 0 && PDY % (16 / dtype_size(dtype)) == 0, "maxpool_bwd: bad args");
+  return NUNET_DISPATCH(dtype, launch_maxpool_bwd, N, H, W, C, x, PX, dy, PDY, dx, PDX, accumulate, (hipStream_t)s);
+}
+
+// ---------------------------------------------------------------------------
+// Upsample x2, bilinear, align_corners=True
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void up_taps(int dst, float scale, int n_in, int& i0, int& i1, float& l1) {
+  const float src = scale * (float)dst;
+  i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, int PX, T* __restrict__ y, int PY, int N, int H, int W, int C) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int G = C / EPV, HO = 2 * H, WO = 2 * W;
+  const float sy = HO > 1 ? (float)(H - 1) / (float)(HO - 1) : 0.f;
+  const float sx = WO > 1 ? (float)(W - 1) / (float)(WO - 1) : 0.f;
+  const int64_t total = (int64_t)N * HO * WO * G;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    const int64_t o = i / G;
+    const int ox = (int)(o % WO);
+    const int64_t t = o / WO;
+    const int oy = (int)(t % HO), n = (int)(t / HO);
+    int y0, y1, x0, x1; float ly, lx;
+    up_taps(oy, sy, H, y0, y1, ly);
+    up_taps(ox, sx, W, x0, x1, lx);
+    const T* b = x + (int64_t)n * H * W * PX + cg * EPV;
+    const Vec16<T> v00 = ld16(b + ((int64_t)y0 * W + x0) * PX), v01 = ld16(b + ((int64_t)y0 * W + x1) * PX);
+    const Vec16<T> v10 = ld16(b + ((int64_t)y1 * W + x0) * PX), v11 = ld16(b + ((int64_t)y1 * W + x1) * PX);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    Vec16<T> r;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e)
+      r.set(e, hy * (hx * v00.get(e) + lx * v01.get(e)) + ly * (hx * v10.get(e) + lx * v11.get(e)));
+    st16(y + o * PY + cg * EPV, r);
+  }
+}
+// gather form of the transposed interpolation: one thread per low-res pixel
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int G = C / EPV, HO = 2 * H, WO = 2 * W;
+  const float sy = HO > 1 ? (float)(H - 1) / (float)(HO - 1) : 0.f;
+  const float sx = WO > 1 ? (float)(W - 1) / (float)(WO - 1) : 0.f;
+  const int64_t total = (int64_t)N * H * W * G;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    const int64_t o = i / G;
+    const int ix = (int)(o % W);
+    const int64_t t = o / W;
+    const int iy = (int)(t % H), n = (int)(t / H);
+    int ylo = 0, yhi = HO - 1, xlo = 0, xhi = WO - 1;
+    if (sy > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / sy) - 1); yhi = min(HO - 1, (int)ceilf((float)(iy + 1) / sy) + 1); }
+    if (sx > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / sx) - 1); xhi = min(WO - 1, (int)ceilf((float)(ix + 1) / sx) + 1); }
+    float acc[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
+    const T* b = dy + (int64_t)n * HO * WO * PDY + cg * EPV;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int y0, y1; float ly;
+      up_taps(oy, sy, H, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int x0, x1; float lx;
+        up_taps(ox, sx, W, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const Vec16<T> g = ld16(b + ((int64_t)oy * WO + ox) * PDY);
+        const float w = wy * wx;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc[e] += w * g.get(e);
+      }
+    }
+    T* q = dx + o * PDX + cg * EPV;
+    Vec16<T> r = accumulate ? ld16(q) : zero16<T>();
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) r.set(e, (accumulate ? r.get(e) : 0.f) + acc[e]);
+    st16(q, r);
+  }
+}
+template <typename T> static int launch_up_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
+  const int64_t total = (int64_t)N * 4 * H * W * (C / Tr<T>::EPV);
+  hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C);
+  return nunet_check_launch("upsample_fwd");
+}
+template <typename T> static int launch_up_bwd(int N, int H, int W, int C, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
+  const int64_t total = (int64_t)N * H * W * (C / Tr<T>::EPV);
+  hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C);
+  return nunet_check_launch("upsample_bwd");
+}
+extern "C" int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s) {
+  int rc = ew_check("upsample_fwd", dtype, N, H, W, C, PX, PY);
+  if (rc) return rc;
+  NUNET_REQUIRE(x && y, "upsample_fwd: null pointer");
+  return NUNET_DISPATCH(dtype, launch_up_fwd, N, H, W, C, x, PX, y, PY, (hipStream_t)s);
+}
+extern "C" int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
+  int rc = ew_check("upsample_bwd", dtype, N, H, W, C, PDY, PDX);
+  if (rc) return rc;
+  NUNET_REQUIRE(dy && dx, "upsample_bwd: null pointer");
+  return NUNET_DISPATCH(dtype, launch_up_bwd, N, H, W, C, dy, PDY, dx, PDX, accumulate, (hipStream_t)s);
+}
+
+// ---------------------------------------------------------------------------
+// 1x1 heads. Lane = channel: 32-lane half-waves walk pixels.
+// ---------------------------------------------------------------------------
+#define HEAD_MAXK 8
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int PX, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ logits, int N, int H, int W, int C, int K) {
+  // thread per pixel; C (=32) channels read as 16-byte vectors
+  constexpr int EPV = Tr<T>::EPV;
+  __shared__ float s_w[HEAD_MAXK * 64];
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) s_w[i] = w[i];
+  __syncthreads();
+  const int64_t hw = (int64_t)H * W, npix = (int64_t)N * hw;
+  for (int64_t pix = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+    float acc[HEAD_MAXK];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXK; ++k) acc[k] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += EPV) {
+      const Vec16<T> v = ld16(x + pix * PX + c0);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const float xv = v.get(e);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXK; ++k)
+          if (k < K) acc[k] += xv * s_w[k * C + c0 + e];
+      }
+    }
+    const int n = (int)(pix / hw);
+    const int64_t rem = pix - n * hw;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXK; ++k)
+      if (k < K) logits[((int64_t)n * K + k) * hw + rem] = acc[k] + b[k];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int PX, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx, int PDX, int accumulate, float* __restrict__ dw, float* __restrict__ db, int N, int H, int W, int C, int K) {
+  // C must be 32: lane&31 = channel
+  const int c = threadIdx.x & 31;
+  const int hwv = threadIdx.x >> 5;  // half-wave in block
+  const int nhw = blockDim.x >> 5;
+  float wk[HEAD_MAXK], aw[HEAD_MAXK], ab[HEAD_MAXK];
+#pragma unroll
+  for (int k = 0; k < HEAD_MAXK; ++k) { wk[k] = k < K ? w[k * C + c] : 0.f; aw[k] = 0.f; ab[k] = 0.f; }
+  const int64_t hw = (int64_t)H * W, npix = (int64_t)N * hw;
+  for (int64_t pix = (int64_t)blockIdx.x * nhw + hwv; pix < npix; pix += (int64_t)gridDim.x * nhw) {
+    const int n = (int)(pix / hw);
+    const int64_t rem = pix - n * hw;
+    const float xv = to_f32(x[pix * PX + c]);
+    float g = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXK; ++k) {
+      if (k < K) {
+        const float d = dl[((int64_t)n * K + k) * hw + rem];
+        g += d * wk[k];
+        aw[k] += d * xv;
+        ab[k] += d;
+      }
+    }
+    if (dx) {
+      T* q = dx + pix * PDX + c;
+      *q = from_f32<T>(accumulate ? to_f32(*q) + g : g);
+    }
+  }
+  for (int k = 0; k < K; ++k) {
+    atomicAdd(&dw[k * C + c], aw[k]);
+    if (c == 0) atomicAdd(&db[k], ab[k]);
+  }
+}
+template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* b, float* logits, hipStream_t st) {
+  hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 256)), dim3(256), 0, st, (const T*)x, PX, w, b, logits, N, H, W, C, K);
+  return nunet_check_launch("head_fwd");
+}
+template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw, float* db, hipStream_t st) {
+  hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 8 * 16, 1024)), dim3(256), 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw, db, N, H, W, C, K);
+  return nunet_check_launch("head_bwd");
+}
+extern "C" int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* b, float* logits, nunet_stream_t s) {
+  NUNET_REQUIRE(x && w && b && logits, "head_fwd: null pointer");
+  NUNET_REQUIRE(C > 0 && C <= 64 && C % (16 / dtype_size(dtype)) == 0 && K >= 1 && K <= HEAD_MAXK, "head_fwd: C=%d K=%d unsupported (C<=64, K<=%d)", C, K, HEAD_MAXK);
+  NUNET_REQUIRE(PX % (16 / dtype_size(dtype)) == 0, "head_fwd: pitch");
+  return NUNET_DISPATCH(dtype, launch_head_fwd, N, H, W, C, K, x, PX, w, b, logits, (hipStream_t)s);
+}
+extern "C" int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* dlogits, void* dx, int32_t PDX, int32_t accumulate, float* dw, float* db, nunet_stream_t s) {
+  NUNET_REQUIRE(x && w && dlogits && dw && db, "head_bwd: null pointer");
+  NUNET_REQUIRE(C == 32 && K >= 1 && K <= HEAD_MAXK, "head_bwd: C=%d K=%d unsupported (C==32, K<=%d)", C, K, HEAD_MAXK);
+  return NUNET_DISPATCH(dtype, launch_head_bwd, N, H, W, C, K, x, PX, w, dlogits, dx, PDX, accumulate, dw, db, (hipStream_t)s);
+}
+
+// ---------------------------------------------------------------------------
+// BCEDiceLoss (losses.py:107-117)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void bce_dice_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, float* __restrict__ ws, int N) {
+  const int n = blockIdx.y;
+  const float* xs = x + (int64_t)n * per;
+  const float* ts = t + (int64_t)n * per;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = xs[i], tv = ts[i];
+    const float pv = sigmoidf_(xv);
+    a0 += pv * tv; a1 += pv; a2 += tv;
+    a3 += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+  __shared__ float s[4][4];
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s[wv][0] = a0; s[wv][1] = a1; s[wv][2] = a2; s[wv][3] = a3; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float v = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+    if (threadIdx.x < 3) atomicAdd(&ws[n * 3 + threadIdx.x], v);
+    else atomicAdd(&ws[N * 3], v);
+  }
+}
+__global__ void bce_dice_final_kernel(const float* __restrict__ ws, int N, int64_t per, float* __restrict__ loss) {
+  // single wave
+  float d = 0.f;
+  for (int n = threadIdx.x; n < N; n += 64) d += (2.f * ws[n * 3] + 1e-5f) / (ws[n * 3 + 1] + ws[n * 3 + 2] + 1e-5f);
+  d = wave_sum(d);
+  if (threadIdx.x == 0) {
+    const float bce = ws[N * 3] / ((float)N * (float)per);
+    loss[0] = 0.5f * bce + (1.f - d / (float)N);
+  }
+}
+__global__ __launch_bounds__(256) void bce_dice_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, const float* __restrict__ ws, const float* __restrict__ gscale, float* __restrict__ dx, int N) {
+  const int n = blockIdx.y;
+  const float I = ws[n * 3], D = ws[n * 3 + 1] + ws[n * 3 + 2] + 1e-5f;
+  const float g = gscale ? gscale[0] : 1.f;
+  const float kb = 0.5f / ((float)N * (float)per);
+  const float num = 2.f * I + 1e-5f;
+  const float invD2 = 1.f / (D * D);
+  const float invN = 1.f / (float)N;
+  const float* xs = x + (int64_t)n * per;
+  const float* ts = t + (int64_t)n * per;
+  float* ds = dx + (int64_t)n * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = xs[i], tv = ts[i];
+    const float pv = sigmoidf_(xv);
+    const float ddice = (2.f * tv * D - num) * invD2 * pv * (1.f - pv);
+    ds[i] = g * (kb * (pv - tv) - invN * ddice);
+  }
+}
+extern "C" size_t nunet_bce_dice_ws_bytes(int32_t N) { return (size_t)(3 * N + 1) * sizeof(float); }
+extern "C" int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int64_t per, float* ws, float* loss, nunet_stream_t s) {
+  NUNET_REQUIRE(logits && target && ws && loss && N > 0 && per > 0, "bce_dice_fwd: bad args");
+  hipStream_t st = (hipStream_t)s;
+  if (hipMemsetAsync(ws, 0, nunet_bce_dice_ws_bytes(N), st) != hipSuccess) { nunet_set_error("bce_dice_fwd: memset failed"); return NUNET_ELAUNCH; }
+  const int gx = grid_for(per, 256 * 4, 64);
+  hipLaunchKernelGGL(bce_dice_partial_kernel, dim3(gx, N), dim3(256), 0, st, logits, target, per, ws, N);
+  hipLaunchKernelGGL(bce_dice_final_kernel, dim3(1), dim3(64), 0, st, ws, N, per, loss);
+  return nunet_check_launch("bce_dice_fwd");
+}
+extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per, const float* ws, const float* gscale, float* dlogits, nunet_stream_t s) {
+  NUNET_REQUIRE(logits && target && ws && dlogits && N > 0 && per > 0, "bce_dice_bwd: bad args");
+  const int gx = grid_for(per, 256 * 4, 64);
+  hipLaunchKernelGGL(bce_dice_bwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)s, logits, target, per, ws, gscale, dlogits, N);
+  return nunet_check_launch("bce_dice_bwd");
+}
+
+// ---------------------------------------------------------------------------
+// iou_score counts (metrics.py:10-14): sigmoid(x) > 0.5  <=>  x > 0
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n, unsigned long long* __restrict__ counts) {
+  unsigned int ci = 0, cu = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool a = x[i] > 0.f, b = t[i] > 0.5f;
+    ci += (a && b) ? 1u : 0u;
+    cu += (a || b) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o); cu += __shfl_xor(cu, o); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], (unsigned long long)ci);
+    atomicAdd(&counts[1], (unsigned long long)cu);
+  }
+}
+extern "C" int nunet_iou_counts(const float* logits, const float* target, int64_t n, unsigned long long* counts, nunet_stream_t s) {
+  NUNET_REQUIRE(logits && target && counts && n > 0, "iou_counts: bad args");
+  hipLaunchKernelGGL(iou_counts_kernel, dim3(grid_for(n, 256 * 4, 256)), dim3(256), 0, (hipStream_t)s, logits, target, n, counts);
+  return nunet_check_launch("iou_counts");
+}
+
+// ---------------------------------------------------------------------------
+// SGD with momentum / weight decay / nesterov (torch.optim.SGD semantics)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, int64_t n, const float* __restrict__ lr_dev, float mom, float wd, int nesterov, int first, float gscale) {
+  const float lr = lr_dev[0];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pv = p[i];
+    float gv = g[i] * gscale + wd * pv;
+    if (mom != 0.f) {
+      const float b = first ? gv : mom * m[i] + gv;
+      m[i] = b;
+      gv = nesterov ? gv + mom * b : b;
+    }
+    p[i] = pv - lr * gv;
+  }
+}
+extern "C" int nunet_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* lr_dev, float momentum, float weight_decay, int32_t nesterov, int32_t first, float grad_scale, nunet_stream_t s) {
+  NUNET_REQUIRE(p && g && lr_dev && n > 0 && (momentum == 0.f || mom), "sgd_step: bad args");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, (hipStream_t)s, p, g, mom, n, lr_dev, momentum, weight_decay, nesterov, first, grad_scale);
+  return nunet_check_launch("sgd_step");
+}

@@ -1,0 +1,460 @@
+// plan.hip — whole-network schedule of NestedUNet / UNet forward and backward
+// (reference finished/archs1.py:35-71 UNet, :74-143 NestedUNet) over the per-op
+// kernels, with a static arena layout:
+//   * one NHWC buffer per pyramid level holding every x_{i,j} of that level as a
+//     channel slot, so torch.cat (archs1.py:116-131) is zero-copy;
+//   * packed KRSC weights (forward + flipped/transposed dgrad copies);
+//   * native-layout fp32 gradient scratch that a single kernel unpacks into the
+//     caller's flat OIHW gradient arena (reference parameters() order).
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+static const int NBF[5] = {32, 64, 128, 256, 512};  // archs1.py:78
+
+// ---------------------------------------------------------------------------
+// batched weight pack / gradient unpack
+// ---------------------------------------------------------------------------
+#define MAXENT 40
+struct PackEnt { long long src, wf, wd; int cout, cin, cinpad, pad_; };
+struct PackTab { int n; int pad_; PackEnt e[MAXENT]; };
+struct UnpackEnt { long long src, dst; int cout, cin, cinpad, taps, nvec, pad_; };
+struct UnpackTab { int n; int accumulate; UnpackEnt e[MAXENT]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ params, T* __restrict__ arena, PackTab tab) {
+  const PackEnt en = tab.e[blockIdx.y];
+  const float* w = params + en.src;
+  const long long nf = 9LL * en.cout * en.cinpad;
+  T* wf = arena + en.wf;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % en.cinpad);
+    const long long t = i / en.cinpad;
+    const int co = (int)(t % en.cout);
+    const int tap = (int)(t / en.cout);
+    wf[i] = from_f32<T>(ci < en.cin ? w[((long long)co * en.cin + ci) * 9 + tap] : 0.f);
+  }
+  if (en.wd >= 0) {
+    T* wd = arena + en.wd;
+    const long long nd = 9LL * en.cout * en.cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nd; i += (long long)gridDim.x * blockDim.x) {
+      const int co = (int)(i % en.cout);
+      const long long t = i / en.cout;
+      const int ci = (int)(t % en.cin);
+      const int tap = (int)(t / en.cin);
+      wd[i] = from_f32<T>(w[((long long)co * en.cin + ci) * 9 + (8 - tap)]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ scratch, float* __restrict__ grads, UnpackTab tab) {
+  const UnpackEnt en = tab.e[blockIdx.y];
+  const float* dw = scratch + en.src;
+  float* g = grads + en.dst;
+  const long long nw = (long long)en.cout * en.cin * en.taps;
+  const long long total = nw + (long long)en.nvec * en.cout;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float v;
+    if (i < nw) {
+      const int tap = (int)(i % en.taps);
+      const long long t = i / en.taps;
+      const int ci = (int)(t % en.cin);
+      const int co = (int)(t / en.cin);
+      v = dw[((long long)tap * en.cout + co) * en.cinpad + ci];
+    } else {
+      v = dw[(long long)en.taps * en.cout * en.cinpad + (i - nw)];
+    }
+    g[i] = tab.accumulate ? g[i] + v : v;
+  }
+}
+
+template <typename T> static int launch_pack(const float* params, void* arena_t, const PackTab& tab, long long maxn, hipStream_t st) {
+  int gx = (int)ceil_div64(maxn, 256 * 4);
+  if (gx > 512) gx = 512;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((pack_kernel<T>), dim3(gx, tab.n), dim3(256), 0, st, params, (T*)arena_t, tab);
+  return nunet_check_launch("pack_weights");
+}
+
+extern "C" int nunet_pack_weights(const float* w, int32_t cout, int32_t cin, int32_t cin_pad, int32_t dtype, void* wf, void* wd, nunet_stream_t s) {
+  NUNET_REQUIRE(w && wf && cout > 0 && cin > 0 && cin_pad >= cin, "pack_weights: bad args");
+  NUNET_REQUIRE(dtype >= 0 && dtype <= 2, "pack_weights: bad dtype");
+  PackTab tab; memset(&tab, 0, sizeof(tab));
+  tab.n = 1;
+  const int es = dtype_size(dtype);
+  char* base = (wd && (char*)wd < (char*)wf) ? (char*)wd : (char*)wf;
+  NUNET_REQUIRE(((char*)wf - base) % es == 0 && (!wd || ((char*)wd - base) % es == 0), "pack_weights: wf/wd misaligned");
+  tab.e[0].src = 0;
+  tab.e[0].wf = ((char*)wf - base) / es;
+  tab.e[0].wd = wd ? ((char*)wd - base) / es : -1;
+  tab.e[0].cout = cout; tab.e[0].cin = cin; tab.e[0].cinpad = cin_pad;
+  return NUNET_DISPATCH(dtype, launch_pack, w, (void*)base, tab, 9LL * cout * cin_pad, (hipStream_t)s);
+}
+
+extern "C" int nunet_unpack_wgrad(const float* dw, int32_t cout, int32_t cin, int32_t cin_pad, float* g, int32_t accumulate, nunet_stream_t s) {
+  NUNET_REQUIRE(dw && g && cout > 0 && cin > 0 && cin_pad >= cin, "unpack_wgrad: bad args");
+  UnpackTab tab; memset(&tab, 0, sizeof(tab));
+  tab.n = 1; tab.accumulate = accumulate;
+  tab.e[0].src = 0; tab.e[0].dst = 0; tab.e[0].cout = cout; tab.e[0].cin = cin; tab.e[0].cinpad = cin_pad; tab.e[0].taps = 9; tab.e[0].nvec = 0;
+  int gx = (int)ceil_div64(9LL * cout * cin, 256 * 4);
+  if (gx > 512) gx = 512;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(unpack_kernel, dim3(gx, 1), dim3(256), 0, (hipStream_t)s, dw, g, tab);
+  return nunet_check_launch("unpack_wgrad");
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct ConvL {
+  int cin, cinpad, cout;
+  long long w_off, b_off, g_off, be_off;  // floats into flat params
+  long long rm_off, rv_off; int bn_index; // floats into bnbuf / index into nbt
+  long long wf, wd;                       // elements of T into the packed-weight region (wd -1: none)
+  long long gs;                           // floats into grad scratch: [dw 9*cout*cinpad][db][dgamma][dbeta]
+  long long stats, save, bsum;            // floats into the fp32 small-vector regions
+};
+struct Node {
+  int i, j;
+  int in_prefix;   // number of level slots concatenated in front (0: encoder input)
+  int out_slot;    // slot of X_i receiving the block output
+  int up_slot;     // slot of X_{i+1} that is upsampled into the concat, -1: none
+  ConvL c1, c2;
+  size_t y1, a1, y2, up, pin;  // arena byte offsets
+};
+struct Head { long long w_off, b_off, gs; int slot; };
+
+struct nunet_plan {
+  nunet_plan_cfg cfg;
+  int es;                       // element size of T
+  int hl[5], wl[5]; long long px[5];
+  int nslots[5], PX[5];
+  std::vector<Node> exec;       // execution order
+  std::vector<int> reg;         // registration (parameter) order -> index into exec
+  std::vector<Head> heads;
+  long long nparams, nbnbuf; int nbn;
+  // arena regions (byte offsets)
+  size_t off_stats, stats_floats;
+  size_t off_gs, gs_floats;     // grad scratch + bn-bwd sums (zeroed every backward)
+  size_t off_save;
+  size_t off_wpack; long long wpack_elems;
+  size_t off_img;
+  size_t X[5], GX[5];
+  size_t off_dy, off_da1, off_gup, off_gpin;
+  size_t total;
+  PackTab ptab; long long pack_maxn;
+  UnpackTab utab; long long unpack_maxn;
+};
+
+static size_t bump(size_t& cur, size_t bytes) {
+  size_t o = align_up(cur, 256);
+  cur = o + bytes;
+  return o;
+}
+
+extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
+  if (!cfg) { nunet_set_error("plan_create: null cfg"); return nullptr; }
+  if (cfg->N <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->H % 16 || cfg->W % 16) {
+    nunet_set_error("plan_create: H=%d W=%d must be positive multiples of 16 (four 2x2 pools, archs1.py:114-131)", cfg->H, cfg->W);
+    return nullptr;
+  }
+  if (cfg->input_channels < 1 || cfg->input_channels > 32) { nunet_set_error("plan_create: input_channels=%d unsupported (1..32)", cfg->input_channels); return nullptr; }
+  if (cfg->num_classes < 1 || cfg->num_classes > 8) { nunet_set_error("plan_create: num_classes=%d unsupported (1..8)", cfg->num_classes); return nullptr; }
+  if (cfg->dtype < 0 || cfg->dtype > 2) { nunet_set_error("plan_create: bad dtype"); return nullptr; }
+  nunet_plan* P = new nunet_plan();
+  P->cfg = *cfg;
+  P->es = dtype_size(cfg->dtype);
+  const bool unet = cfg->unet != 0;
+  for (int i = 0; i < 5; ++i) {
+    P->hl[i] = cfg->H >> i; P->wl[i] = cfg->W >> i;
+    P->px[i] = (long long)cfg->N * P->hl[i] * P->wl[i];
+    P->nslots[i] = unet ? (i == 4 ? 1 : 2) : 5 - i;
+    P->PX[i] = P->nslots[i] * NBF[i];
+  }
+  // ---- nodes in execution order ------------------------------------------------
+  if (!unet) {
+    for (int s = 0; s < 5; ++s)
+      for (int j = 0; j <= s; ++j) {
+        Node n; memset(&n, 0, sizeof(n));
+        n.i = s - j; n.j = j; n.in_prefix = j; n.out_slot = j; n.up_slot = j > 0 ? j - 1 : -1;
+        P->exec.push_back(n);
+      }
+  } else {
+    for (int i = 0; i < 5; ++i) { Node n; memset(&n, 0, sizeof(n)); n.i = i; n.j = 0; n.in_prefix = 0; n.out_slot = 0; n.up_slot = -1; P->exec.push_back(n); }
+    for (int i = 3; i >= 0; --i) {
+      Node n; memset(&n, 0, sizeof(n));
+      n.i = i; n.j = 4 - i; n.in_prefix = 1; n.out_slot = 1; n.up_slot = (i + 1 == 4) ? 0 : 1;
+      P->exec.push_back(n);
+    }
+  }
+  // registration order: by column j, then row i (archs1.py:45-56 / 85-103)
+  for (int j = 0; j < 5; ++j)
+    for (int i = 0; i < 5; ++i)
+      for (size_t k = 0; k < P->exec.size(); ++k)
+        if (P->exec[k].i == i && P->exec[k].j == j) P->reg.push_back((int)k);
+
+  // ---- parameter / buffer offsets in registration order -------------------------
+  long long po = 0, bo = 0, gs = 0, sv = 0; int bn = 0;
+  long long wp = 0;
+  auto setup_conv = [&](ConvL& c, int cin, int cout, bool need_wd) {
+    c.cin = cin; c.cout = cout; c.cinpad = cin < 32 ? 32 : cin;
+    c.w_off = po; po += (long long)cout * cin * 9;
+    c.b_off = po; po += cout;
+    c.g_off = po; po += cout;
+    c.be_off = po; po += cout;
+    c.rm_off = bo; bo += cout; c.rv_off = bo; bo += cout; c.bn_index = bn++;
+    c.wf = wp; wp += 9LL * cout * c.cinpad; wp = (wp + 127) / 128 * 128;
+    if (need_wd) { c.wd = wp; wp += 9LL * cout * cin; wp = (wp + 127) / 128 * 128; } else c.wd = -1;
+    c.gs = gs; gs += 9LL * cout * c.cinpad + 3LL * cout;
+    c.stats = sv; c.save = sv; c.bsum = sv; sv += 2LL * cout;
+  };
+  for (size_t r = 0; r < P->reg.size(); ++r) {
+    Node& n = P->exec[P->reg[r]];
+    const int f = NBF[n.i];
+    int cin;
+    if (n.in_prefix == 0) cin = n.i == 0 ? cfg->input_channels : NBF[n.i - 1];
+    else cin = n.in_prefix * f + NBF[n.i + 1];
+    setup_conv(n.c1, cin, f, !(n.i == 0 && n.j == 0));
+    setup_conv(n.c2, f, f, true);
+  }
+  const int nheads = (cfg->deep_supervision && !unet) ? 4 : 1;
+  for (int k = 0; k < nheads; ++k) {
+    Head h;
+    h.w_off = po; po += (long long)cfg->num_classes * NBF[0];
+    h.b_off = po; po += cfg->num_classes;
+    h.gs = gs; gs += (long long)cfg->num_classes * NBF[0] + cfg->num_classes;
+    h.slot = unet ? 1 : (nheads == 4 ? k + 1 : 4);
+    P->heads.push_back(h);
+  }
+  P->nparams = po; P->nbnbuf = bo; P->nbn = bn;
+  P->wpack_elems = wp;
+
+  // ---- arena ---------------------------------------------------------------------
+  size_t cur = 0;
+  P->stats_floats = (size_t)sv;
+  P->off_stats = bump(cur, P->stats_floats * 4);
+  P->gs_floats = (size_t)gs + (size_t)sv;  // grad scratch followed by bn-bwd sums
+  P->off_gs = bump(cur, P->gs_floats * 4);
+  P->off_save = bump(cur, (size_t)sv * 4);
+  P->off_wpack = bump(cur, (size_t)wp * P->es);
+  P->off_img = bump(cur, (size_t)P->px[0] * 32 * P->es);
+  for (int i = 0; i < 5; ++i) {
+    P->X[i] = bump(cur, (size_t)P->px[i] * P->PX[i] * P->es);
+    P->GX[i] = bump(cur, (size_t)P->px[i] * P->PX[i] * P->es);
+  }
+  size_t max_dy = 0, max_gup = 0, max_gpin = 0;
+  for (size_t k = 0; k < P->exec.size(); ++k) {
+    Node& n = P->exec[k];
+    const int f = NBF[n.i];
+    const size_t plane = (size_t)P->px[n.i] * f * P->es;
+    n.y1 = bump(cur, plane); n.a1 = bump(cur, plane); n.y2 = bump(cur, plane);
+    if (n.up_slot >= 0) { n.up = bump(cur, (size_t)P->px[n.i] * NBF[n.i + 1] * P->es); if ((size_t)P->px[n.i] * NBF[n.i + 1] * P->es > max_gup) max_gup = (size_t)P->px[n.i] * NBF[n.i + 1] * P->es; }
+    if (n.in_prefix == 0 && n.i > 0) { n.pin = bump(cur, (size_t)P->px[n.i] * NBF[n.i - 1] * P->es); if ((size_t)P->px[n.i] * NBF[n.i - 1] * P->es > max_gpin) max_gpin = (size_t)P->px[n.i] * NBF[n.i - 1] * P->es; }
+    if (plane > max_dy) max_dy = plane;
+  }
+  P->off_dy = bump(cur, max_dy);
+  P->off_da1 = bump(cur, max_dy);
+  P->off_gup = bump(cur, max_gup ? max_gup : 256);
+  P->off_gpin = bump(cur, max_gpin ? max_gpin : 256);
+  P->total = align_up(cur, 256);
+
+  // ---- pack / unpack tables ------------------------------------------------------
+  memset(&P->ptab, 0, sizeof(P->ptab)); memset(&P->utab, 0, sizeof(P->utab));
+  P->pack_maxn = 0; P->unpack_maxn = 0;
+  auto add_conv = [&](const ConvL& c) {
+    PackEnt& pe = P->ptab.e[P->ptab.n++];
+    pe.src = c.w_off; pe.wf = c.wf; pe.wd = c.wd; pe.cout = c.cout; pe.cin = c.cin; pe.cinpad = c.cinpad;
+    if (9LL * c.cout * c.cinpad > P->pack_maxn) P->pack_maxn = 9LL * c.cout * c.cinpad;
+    UnpackEnt& ue = P->utab.e[P->utab.n++];
+    ue.src = c.gs; ue.dst = c.w_off; ue.cout = c.cout; ue.cin = c.cin; ue.cinpad = c.cinpad; ue.taps = 9; ue.nvec = 3;
+    if (9LL * c.cout * c.cin + 3 * c.cout > P->unpack_maxn) P->unpack_maxn = 9LL * c.cout * c.cin + 3 * c.cout;
+  };
+  for (size_t r = 0; r < P->reg.size(); ++r) { add_conv(P->exec[P->reg[r]].c1); add_conv(P->exec[P->reg[r]].c2); }
+  for (size_t k = 0; k < P->heads.size(); ++k) {
+    UnpackEnt& ue = P->utab.e[P->utab.n++];
+    ue.src = P->heads[k].gs; ue.dst = P->heads[k].w_off; ue.cout = cfg->num_classes; ue.cin = NBF[0]; ue.cinpad = NBF[0]; ue.taps = 1; ue.nvec = 1;
+  }
+  return P;
+}
+
+extern "C" void nunet_plan_destroy(nunet_plan* p) { delete p; }
+extern "C" size_t nunet_plan_arena_bytes(const nunet_plan* p) { return p ? p->total : 0; }
+extern "C" int64_t nunet_plan_param_count(const nunet_plan* p) { return p ? p->nparams : 0; }
+extern "C" int64_t nunet_plan_bnbuf_count(const nunet_plan* p) { return p ? p->nbnbuf : 0; }
+extern "C" int32_t nunet_plan_bn_layers(const nunet_plan* p) { return p ? p->nbn : 0; }
+extern "C" int32_t nunet_plan_num_heads(const nunet_plan* p) { return p ? (int32_t)p->heads.size() : 0; }
+extern "C" int64_t nunet_plan_feature(const nunet_plan* p, int32_t i, int32_t j, int32_t* pitch, int32_t* channels) {
+  if (!p || i < 0 || i > 4) return -1;
+  for (size_t k = 0; k < p->exec.size(); ++k)
+    if (p->exec[k].i == i && p->exec[k].j == j) {
+      if (pitch) *pitch = p->PX[i];
+      if (channels) *channels = NBF[i];
+      return (int64_t)(p->X[i] + (size_t)p->exec[k].out_slot * NBF[i] * p->es);
+    }
+  return -1;
+}
+
+#define CK(expr)                \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != NUNET_OK) return rc_; \
+  } while (0)
+
+static inline char* AB(void* arena, size_t off) { return (char*)arena + off; }
+
+extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnbuf, int64_t* nbt, const float* input, void* arena, float* logits, int32_t training, nunet_stream_t s) {
+  NUNET_REQUIRE(P && params && input && arena && logits, "plan_forward: null pointer");
+  NUNET_REQUIRE(bnbuf, "plan_forward: bnbuf (running stats) required");
+  hipStream_t st = (hipStream_t)s;
+  const nunet_plan_cfg& c = P->cfg;
+  const int dt = c.dtype, es = P->es;
+  float* stats = (float*)AB(arena, P->off_stats);
+  float* save = (float*)AB(arena, P->off_save);
+  char* wpack = AB(arena, P->off_wpack);
+  if (training) {
+    if (hipMemsetAsync(stats, 0, P->stats_floats * 4, st) != hipSuccess) { nunet_set_error("plan_forward: memset failed"); return NUNET_ELAUNCH; }
+  }
+  if (dt == NUNET_F32) CK(launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, st));
+  else if (dt == NUNET_BF16) CK(launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, st));
+  else CK(launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, st));
+  CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, s));
+
+  for (size_t k = 0; k < P->exec.size(); ++k) {
+    const Node& n = P->exec[k];
+    const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
+    if (n.up_slot >= 0)
+      CK(nunet_upsample2x_fwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1],
+                              AB(arena, P->X[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1],
+                              AB(arena, n.up), NBF[i + 1], s));
+    for (int cv = 0; cv < 2; ++cv) {
+      const ConvL& L = cv == 0 ? n.c1 : n.c2;
+      nunet_conv_desc d; memset(&d, 0, sizeof(d));
+      d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
+      if (cv == 1) { d.src0 = AB(arena, n.a1); d.C0 = f; d.P0 = f; }
+      else if (n.in_prefix == 0) {
+        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; }
+        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; }
+      } else {
+        d.src0 = AB(arena, P->X[i]); d.C0 = n.in_prefix * f; d.P0 = P->PX[i];
+        d.src1 = AB(arena, n.up); d.C1 = NBF[i + 1]; d.P1 = NBF[i + 1];
+      }
+      d.wpack = wpack + (size_t)L.wf * es;
+      d.bias = params + L.b_off;
+      d.dst0 = AB(arena, cv == 0 ? n.y1 : n.y2); d.D0 = f; d.Q0 = f;
+      d.stats = training ? stats + L.stats : nullptr;
+      CK(nunet_conv3x3_fwd(&d, s));
+
+      nunet_bn_fwd_desc b; memset(&b, 0, sizeof(b));
+      b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
+      b.y = d.dst0; b.PY = f; b.conv_bias = params + L.b_off; b.stats = stats + L.stats;
+      b.gamma = params + L.g_off; b.beta = params + L.be_off;
+      b.running_mean = bnbuf + L.rm_off; b.running_var = bnbuf + L.rv_off;
+      b.num_batches_tracked = nbt ? nbt + L.bn_index : nullptr;
+      b.save_mean_invstd = save + L.save; b.training = training; b.momentum = 0.1f; b.eps = 1e-5f;
+      if (cv == 0) { b.a = AB(arena, n.a1); b.PA = f; }
+      else {
+        b.a = AB(arena, P->X[i] + (size_t)n.out_slot * f * es); b.PA = P->PX[i];
+        if (n.in_prefix == 0 && i < 4) {  // encoder column: feed the next level (archs1.py:115,118,122,127)
+          for (size_t q = 0; q < P->exec.size(); ++q)
+            if (P->exec[q].i == i + 1 && P->exec[q].in_prefix == 0) { b.pooled = AB(arena, P->exec[q].pin); b.PP = f; }
+        }
+      }
+      CK(nunet_bn_relu_fwd(&b, s));
+    }
+  }
+  const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
+  for (size_t k = 0; k < P->heads.size(); ++k)
+    CK(nunet_head_fwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)P->heads[k].slot * NBF[0] * es), P->PX[0],
+                      params + P->heads[k].w_off, params + P->heads[k].b_off, logits + plane * k, s));
+  return NUNET_OK;
+}
+
+extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, nunet_stream_t s) {
+  NUNET_REQUIRE(P && params && dlogits && arena && grads, "plan_backward: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  const nunet_plan_cfg& c = P->cfg;
+  const int dt = c.dtype, es = P->es;
+  float* gsr = (float*)AB(arena, P->off_gs);
+  float* bsums = gsr + (P->gs_floats - P->stats_floats);
+  float* save = (float*)AB(arena, P->off_save);
+  char* wpack = AB(arena, P->off_wpack);
+  if (hipMemsetAsync(gsr, 0, P->gs_floats * 4, st) != hipSuccess) { nunet_set_error("plan_backward: memset failed"); return NUNET_ELAUNCH; }
+  bool written[5][5]; memset(written, 0, sizeof(written));
+
+  const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
+  for (size_t k = 0; k < P->heads.size(); ++k) {
+    const Head& h = P->heads[k];
+    CK(nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
+                      params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
+                      written[0][h.slot] ? 1 : 0, gsr + h.gs, gsr + h.gs + (long long)c.num_classes * NBF[0], s));
+    written[0][h.slot] = true;
+  }
+
+  for (int k = (int)P->exec.size() - 1; k >= 0; --k) {
+    const Node& n = P->exec[k];
+    const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
+    NUNET_REQUIRE(written[i][n.out_slot], "plan_backward: internal: grad of x%d_%d never produced", n.i, n.j);
+    for (int cv = 1; cv >= 0; --cv) {
+      const ConvL& L = cv == 0 ? n.c1 : n.c2;
+      // BN + ReLU backward
+      nunet_bn_bwd_desc b; memset(&b, 0, sizeof(b));
+      b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
+      if (cv == 1) { b.da = AB(arena, P->GX[i] + (size_t)n.out_slot * f * es); b.PDA = P->PX[i]; b.y = AB(arena, n.y2); }
+      else { b.da = AB(arena, P->off_da1); b.PDA = f; b.y = AB(arena, n.y1); }
+      b.PY = f; b.mean_invstd = save + L.save; b.gamma = params + L.g_off; b.beta = params + L.be_off;
+      b.sums = bsums + L.bsum;
+      float* gl = gsr + L.gs + 9LL * L.cout * L.cinpad;
+      b.dbias = gl; b.dgamma = gl + L.cout; b.dbeta = gl + 2 * L.cout;
+      b.dy = AB(arena, P->off_dy); b.PDY = f;
+      CK(nunet_bn_relu_bwd_reduce(&b, s));
+      CK(nunet_bn_relu_bwd_apply(&b, s));
+      // wgrad
+      nunet_wgrad_desc w; memset(&w, 0, sizeof(w));
+      w.dtype = dt; w.N = c.N; w.H = H; w.W = W;
+      if (cv == 1) { w.src0 = AB(arena, n.a1); w.C0 = f; w.P0 = f; }
+      else if (n.in_prefix == 0) {
+        if (i == 0) { w.src0 = AB(arena, P->off_img); w.C0 = 32; w.P0 = 32; }
+        else { w.src0 = AB(arena, n.pin); w.C0 = NBF[i - 1]; w.P0 = NBF[i - 1]; }
+      } else {
+        w.src0 = AB(arena, P->X[i]); w.C0 = n.in_prefix * f; w.P0 = P->PX[i];
+        w.src1 = AB(arena, n.up); w.C1 = NBF[i + 1]; w.P1 = NBF[i + 1];
+      }
+      w.dy = b.dy; w.Cout = f; w.PY = f; w.dw = gsr + L.gs;
+      CK(nunet_conv3x3_wgrad(&w, s));
+      // dgrad
+      if (cv == 0 && i == 0 && n.in_prefix == 0) continue;  // no gradient into the image
+      nunet_conv_desc d; memset(&d, 0, sizeof(d));
+      d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
+      d.src0 = b.dy; d.C0 = f; d.P0 = f;
+      d.wpack = wpack + (size_t)L.wd * es;
+      if (cv == 1) { d.dst0 = AB(arena, P->off_da1); d.D0 = f; d.Q0 = f; }
+      else if (n.in_prefix == 0) { d.dst0 = AB(arena, P->off_gpin); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1]; }
+      else {
+        d.dst0 = AB(arena, P->GX[i]); d.D0 = n.in_prefix * f; d.Q0 = P->PX[i]; d.acc_slot_w = f;
+        for (int q = 0; q < n.in_prefix; ++q) { if (written[i][q]) d.acc0_mask |= 1u << q; written[i][q] = true; }
+        d.dst1 = AB(arena, P->off_gup); d.D1 = NBF[i + 1]; d.Q1 = NBF[i + 1];
+      }
+      CK(nunet_conv3x3_fwd(&d, s));
+      if (cv == 0) {
+        if (n.in_prefix == 0) {
+          // through MaxPool2d(2,2) into x_{i-1,0}
+          CK(nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
+                                  AB(arena, P->off_gpin), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], written[i - 1][0] ? 1 : 0, s));
+          written[i - 1][0] = true;
+        } else {
+          // through the bilinear upsample into x_{i+1,up_slot}
+          CK(nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup), NBF[i + 1],
+                                  AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], written[i + 1][n.up_slot] ? 1 : 0, s));
+          written[i + 1][n.up_slot] = true;
+        }
+      }
+    }
+  }
+  P->utab.accumulate = accumulate;
+  int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(unpack_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, gsr, grads, P->utab);
+  return nunet_check_launch("unpack_grads");
+}

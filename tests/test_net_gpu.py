@@ -1,0 +1,245 @@
+"""Whole-path parity on the MI355X: NestedUNet / UNet forward, loss, IoU, gradients,
+BN running statistics and short SGD trajectories against (a) golden vectors captured
+from the imported reference and (b) the CPU oracle in fp64 on the same seeded inputs.
+
+Tolerances. north_star asks for logits within 1e-4 (fp32) of the reference CPU
+forward; that is asserted directly on the goldens. Gradients of this network are
+ill-conditioned in fp32 (the reference's own fp32 gradients sit ~4e-3 relative from
+an fp64 evaluation), so gradient parity is asserted against the fp64
+oracle with the bound max(3 x reference-fp32 error, 2e-3) per tensor."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import nunet_amd  # noqa: E402
+from nunet_amd import _lib as L  # noqa: E402
+from conftest import GOLDEN_CASES, load_golden  # noqa: E402
+from oracle import nunet_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def build(cfg, synth, dtype="fp32", unet=False):
+    n, h, w, cin, ncls, ds, train, fresh = cfg
+    cls = nunet_amd.archs.UNet if unet else nunet_amd.archs.NestedUNet
+    m = cls(ncls, cin, ds, dtype=dtype)
+    st = synth.closed_form_state(ncls, cin, ds, fresh)
+    if unet:
+        keep = set(m.state_dict().keys())
+        st = {k: v for k, v in st.items() if k in keep}
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
+    m = m.to(DEV)
+    img, msk = synth.synth_batch(n, h, w, cin, ncls, seed=1234)
+    return m, st, torch.from_numpy(img), torch.from_numpy(msk)
+
+
+def run_step(m, x, t, ds):
+    crit = nunet_amd.losses.BCEDiceLoss()
+    out = m(x.to(DEV))
+    tg = t.to(DEV)
+    if ds:
+        loss = 0
+        for o in out:
+            loss = loss + crit(o, tg)
+        loss = loss / len(out)
+        last = out[-1]
+    else:
+        loss = crit(out, tg)
+        last = out
+    iou = nunet_amd.metrics.iou_score(last, tg)
+    m.zero_grad()
+    loss.backward()
+    return out, loss, iou
+
+
+@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+def test_fp32_matches_reference_goldens(name, synth):
+    cfg = GOLDEN_CASES[name]
+    n, h, w, cin, ncls, ds, train, fresh = cfg
+    g = load_golden(name)
+    m, st, x, t = build(cfg, synth)
+    if not train:
+        m.eval()
+        with torch.no_grad():
+            o = m(x.to(DEV))
+        scale = max(1.0, float(np.abs(g["logits0"]).max()))
+        assert float(np.abs(o.cpu().numpy() - g["logits0"]).max()) < 1e-4 * scale
+        loss = nunet_amd.losses.BCEDiceLoss()(o, t.to(DEV))
+        assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, float(g["loss"]))
+        assert abs(nunet_amd.metrics.iou_score(o, t.to(DEV)) - float(g["iou"])) < 5e-3
+        return
+    m.train()
+    out, loss, iou = run_step(m, x, t, ds)
+    outs = out if ds else [out]
+    for k, o in enumerate(outs):
+        ref = g["logits%d" % k]
+        assert float(np.abs(o.detach().cpu().numpy() - ref).max()) < 1e-4 * max(1.0, float(np.abs(ref).max())), (name, k)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    # IoU is a hard threshold on logits: allow the flip of a handful of near-zero logits
+    assert abs(iou - float(g["iou"])) < 5e-3
+    # BN running statistics after one step
+    sd = m.state_dict()
+    for k, nm in enumerate(str(s) for s in g["bn_names"]):
+        assert abs(float(sd[nm].double().sum()) - g["bn_sum"][k]) < 2e-4 * (1 + abs(g["bn_sum"][k])), nm
+    for key in g.files:
+        if key.startswith("bn/"):
+            np.testing.assert_allclose(sd[key[3:]].cpu().numpy(), g[key], rtol=2e-4, atol=2e-6, err_msg=key)
+    # gradients vs the fp64 oracle, bounded by the reference's own fp32 error
+    o64 = O.OracleNet(st, ncls, cin, ds, dtype=torch.float64)
+    l64, _ = O.criterion_ds(o64(x.double()), t.double())
+    l64.backward()
+    o32 = O.OracleNet(st, ncls, cin, ds, dtype=torch.float32)
+    l32, _ = O.criterion_ds(o32(x), t)
+    l32.backward()
+    names = [str(s) for s in g["grad_names"]]
+    worst = 0.0
+    for k, (nm, p) in enumerate(m.named_parameters()):
+        assert nm == names[k]
+        g64 = o64.params[nm].grad
+        g32 = o32.params[nm].grad.double()
+        mine = p.grad.detach().cpu().double()
+        nrm = float(g64.norm())
+        if nm.endswith("conv1.bias") or nm.endswith("conv2.bias"):
+            # analytically zero (BatchNorm follows); only rounding noise, must stay tiny
+            assert float(mine.abs().max()) < 1e-4, nm
+            continue
+        err_ref = float((g32 - g64).norm()) / (nrm + 1e-30)
+        err_mine = float((mine - g64).norm()) / (nrm + 1e-30)
+        worst = max(worst, err_mine)
+        assert err_mine < max(3 * err_ref, 2e-3), (nm, err_mine, err_ref)
+        # the golden (reference fp32) summary agrees too
+        assert abs(float(mine.norm()) - g["grad_l2"][k]) < 0.03 * g["grad_l2"][k] + 1e-7, nm
+    print(name, "worst grad rel err vs fp64 oracle:", worst)
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 6e-2), ("fp16", 1e-2)])
+def test_reduced_precision_forward_and_grads(dtype, tol, synth):
+    cfg = GOLDEN_CASES["a_n2_32x32_k1"]
+    g = load_golden("a_n2_32x32_k1")
+    m, st, x, t = build(cfg, synth, dtype=dtype)
+    m.train()
+    out, loss, iou = run_step(m, x, t, False)
+    ref = g["logits0"]
+    assert float(np.abs(out.detach().cpu().numpy() - ref).max()) < tol * float(np.abs(ref).max())
+    assert abs(float(loss) - float(g["loss"])) < tol
+    o64 = O.OracleNet(st, 1, 3, False, dtype=torch.float64)
+    O.bce_dice_loss(o64(x.double()), t.double()).backward()
+    errs = []
+    for nm, p in m.named_parameters():
+        if nm.endswith("conv1.bias") or nm.endswith("conv2.bias"):
+            continue
+        g64 = o64.params[nm].grad
+        errs.append(float((p.grad.cpu().double() - g64).norm() / (g64.norm() + 1e-30)))
+    # cosine-level agreement of every gradient tensor with the fp64 oracle
+    assert max(errs) < (0.35 if dtype == "bf16" else 0.08), max(errs)
+    assert float(np.median(errs)) < (0.12 if dtype == "bf16" else 0.02)
+
+
+def test_features_match_oracle(synth):
+    """Every block output x_{i,j} (NHWC level-buffer slots) vs the oracle's features."""
+    cfg = GOLDEN_CASES["a_n2_32x32_k1"]
+    m, st, x, t = build(cfg, synth)
+    m.train()
+    with torch.no_grad():
+        m(x.to(DEV))
+    pl = m.plan_for(x.to(DEV))
+    o64 = O.OracleNet(st, 1, 3, False, dtype=torch.float64)
+    o64(x.double())
+    for (i, j), f in o64.features.items():
+        got = pl.feature(i, j).float().permute(0, 3, 1, 2).cpu().double()
+        err = float((got - f.detach()).abs().max() / f.detach().abs().max())
+        assert err < 2e-4, ((i, j), err)
+
+
+def test_unet_matches_oracle(synth):
+    """Plain U-Net (reference finished/archs1.py:35-71) shares every kernel."""
+    import torch.nn.functional as F
+    cfg = (2, 32, 32, 3, 1, False, True, True)
+    m, st, x, t = build(cfg, synth, unet=True)
+    m.train()
+    out, loss, iou = run_step(m, x, t, False)
+    # oracle: the nested oracle's block primitive on the U-Net wiring
+    net = O.OracleNet(st, 1, 3, False, dtype=torch.float64)
+    xs = {}
+    inp = x.double()
+    for i in range(5):
+        xs[i] = net._block(inp if i == 0 else F.max_pool2d(xs[i - 1], 2, 2), i, 0)
+    d = xs[4]
+    for i in (3, 2, 1, 0):
+        up = F.interpolate(d, scale_factor=2, mode="bilinear", align_corners=True)
+        d = net._block(torch.cat([xs[i], up], 1), i, 4 - i)
+    ref = F.conv2d(d, net.params["final.weight"], net.params["final.bias"])
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 1e-4
+    l64 = O.bce_dice_loss(ref, t.double())
+    l64.backward()
+    assert abs(float(loss) - float(l64)) < 2e-5
+    for nm, p in m.named_parameters():
+        if nm.endswith("conv1.bias") or nm.endswith("conv2.bias"):
+            continue
+        g64 = net.params[nm].grad
+        assert float((p.grad.cpu().double() - g64).norm() / g64.norm()) < 2e-2, nm
+
+
+def test_trajectory_against_reference(synth):
+    """8 SGD steps + cosine schedule (reference trains.py:113-135,229-239,323-324).
+    The loop is chaotic at the 1e-3 level (fp32 reference vs fp64 evaluation of the
+    same loop differ by up to 1e-2 in loss after 8 steps), hence the band."""
+    g = load_golden("trajectory_n4_32x32")
+    m = nunet_amd.archs.NestedUNet(1, 3, False)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.closed_form_state(1, 3, False, True).items()})
+    m = m.to(DEV)
+    opt = torch.optim.SGD(filter(lambda p: p.requires_grad, m.parameters()), lr=1e-3, momentum=0.9,
+                          nesterov=False, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=4, eta_min=1e-5)
+    crit = nunet_amd.losses.BCEDiceLoss()
+    meter = nunet_amd.utils.AverageMeter()
+    step = 0
+    for ep in range(4):
+        m.train()
+        for _ in range(2):
+            img, msk = synth.synth_batch(4, 32, 32, 3, 1, seed=1234 + step)
+            x, t = torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV)
+            out = m(x)
+            loss = crit(out, t)
+            iou = nunet_amd.metrics.iou_score(out, t)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            meter.update(loss.item(), 4)
+            assert abs(opt.param_groups[0]["lr"] - g["lr"][step]) < 1e-12
+            assert abs(loss.item() - g["loss"][step]) < (1e-4 if step < 2 else 2e-2), (step, loss.item(), g["loss"][step])
+            assert abs(iou - g["iou"][step]) < (5e-3 if step < 2 else 5e-2)
+            step += 1
+        sched.step()
+    m.eval()
+    img, msk = synth.synth_batch(4, 32, 32, 3, 1, seed=99)
+    with torch.no_grad():
+        o = m(torch.from_numpy(img).to(DEV))
+    vloss = float(crit(o, torch.from_numpy(msk).to(DEV)))
+    assert abs(vloss - float(g["val_loss"])) < 3e-2
+    # state_dict round trip into a fresh module (reference trains.py:345 / val.py:58)
+    m2 = nunet_amd.archs.NestedUNet(1, 3, False)
+    m2.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    m2 = m2.to(DEV).eval()
+    with torch.no_grad():
+        o2 = m2(torch.from_numpy(img).to(DEV))
+    assert torch.equal(o, o2)
+
+
+def test_grad_accumulation_and_zero_grad_semantics(synth):
+    cfg = GOLDEN_CASES["a_n2_32x32_k1"]
+    m, st, x, t = build(cfg, synth)
+    m.train()
+    run_step(m, x, t, False)
+    g1 = [p.grad.clone() for p in m.parameters()]
+    crit = nunet_amd.losses.BCEDiceLoss()
+    # second backward without zero_grad accumulates (autograd semantics)
+    crit(m(x.to(DEV)), t.to(DEV)).backward()
+    for p, a in zip(m.parameters(), g1):
+        assert float((p.grad - 2 * a).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-8
+    m.zero_grad(set_to_none=False)
+    crit(m(x.to(DEV)), t.to(DEV)).backward()
+    for p, a in zip(m.parameters(), g1):
+        assert float((p.grad - a).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-8

@@ -1,0 +1,377 @@
+"""Per-kernel parity: every C-ABI entry of libnunet.so against the CPU oracle ops
+(stock torch fp32/fp64 on CPU) on seeded inputs. Runs on the MI355X only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import nunet_amd  # noqa: E402
+from nunet_amd import _lib as L  # noqa: E402
+
+DEV = "cuda:0"
+TOL = {L.F32: 2e-5, L.BF16: 1.2e-2, L.F16: 2e-3}   # relative to the output's max |value|
+DT = {L.F32: "fp32", L.BF16: "bf16", L.F16: "fp16"}
+
+
+def tdt(dt):
+    return L.TORCH_DTYPE[dt]
+
+
+def nhwc(x, dt, pitch=None, off=0):
+    """NCHW fp32 CPU tensor -> NHWC `dt` GPU buffer with optional channel pitch/offset.
+    Returns (buffer, view_of_the_channels)."""
+    n, c, h, w = x.shape
+    pitch = pitch or c
+    buf = torch.zeros((n, h, w, pitch), dtype=tdt(dt), device=DEV)
+    buf[..., off:off + c] = x.permute(0, 2, 3, 1).to(DEV).to(tdt(dt))
+    return buf
+
+
+def to_nchw(buf, c, off=0):
+    return buf[..., off:off + c].float().permute(0, 3, 1, 2).cpu()
+
+
+def q(x, dt):
+    """round-trip through the storage dtype (what the kernel actually sees)"""
+    return x.to(tdt(dt)).float()
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def pack(w, dt, cin_pad=None, want_wd=True):
+    cout, cin = w.shape[:2]
+    cin_pad = cin_pad or cin
+    wg = w.contiguous().to(DEV)
+    wf = torch.zeros(9 * cout * cin_pad, dtype=tdt(dt), device=DEV)
+    wd = torch.zeros(9 * cout * cin, dtype=tdt(dt), device=DEV) if want_wd else None
+    L.check(L.lib().nunet_pack_weights(L.ptr(wg), cout, cin, cin_pad, dt, L.ptr(wf), L.ptr(wd), L.stream()), "pack")
+    return wf, wd
+
+
+def conv_desc(dt, n, h, w, src0, c0, p0, wpack, dst0, d0, q0, src1=None, c1=0, p1=0, bias=None,
+              dst1=None, d1=0, q1=0, slot_w=0, mask=0, acc1=0, stats=None):
+    return L.ConvDesc(dt, n, h, w, L.ptr(src0), c0, p0, L.ptr(src1), c1, p1, L.ptr(wpack), L.ptr(bias),
+                      L.ptr(dst0), d0, q0, L.ptr(dst1), d1, q1, slot_w, mask, acc1, L.ptr(stats))
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
+@pytest.mark.parametrize("shape", [
+    (2, 20, 24, 32, 0, 32),     # BN=32 config, ragged tiles
+    (1, 16, 16, 64, 64, 64),    # two sources, BN=64 config
+    (5, 6, 6, 32, 0, 64),       # multi-image tiles
+    (2, 8, 40, 16, 0, 32),      # Cin = 16 (single half chunk)
+    (1, 2, 2, 64, 32, 96),      # tiny spatial, Cout = 96 -> BN=32 config
+    (3, 1, 1, 32, 0, 32),       # 1x1 images (level 4 of a 16x16 input)
+])
+def test_conv3x3_fwd(dt, shape):
+    n, h, w, c0, c1, cout = shape
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    cin = c0 + c1
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    # source 0 lives in a wider level buffer (pitch > C0), source 1 is dense
+    s0 = nhwc(x[:, :c0], dt, pitch=c0 + 32, off=0)
+    s1 = nhwc(x[:, c0:], dt) if c1 else None
+    wf, _ = pack(wt, dt)
+    y = torch.full((n, h, w, cout), 7.0, dtype=tdt(dt), device=DEV)
+    stats = torch.zeros(2 * cout, dtype=torch.float32, device=DEV)
+    bg = b.to(DEV)
+    d = conv_desc(dt, n, h, w, s0, c0, c0 + 32, wf, y, cout, cout, src1=s1, c1=c1, p1=c1, bias=bg, stats=stats)
+    L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "conv")
+    ref = F.conv2d(q(x, dt).double(), q(wt, dt).double(), b.double(), padding=1)
+    got = to_nchw(y, cout)
+    assert rel_err(got, ref) < TOL[dt], (DT[dt], shape)
+    # BN partial sums are taken about the bias on the rounded outputs
+    dd = got.double() - b.double().view(1, -1, 1, 1)
+    s = stats.cpu().double()
+    m = n * h * w
+    np.testing.assert_allclose(s[:cout].numpy() / m, dd.sum((0, 2, 3)).numpy() / m, atol=1e-4 * float(dd.abs().max()) + 1e-6)
+    np.testing.assert_allclose(s[cout:].numpy() / m, (dd * dd).sum((0, 2, 3)).numpy() / m, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+def test_conv3x3_dgrad_split_accumulate(dt):
+    """dgrad = conv with the flipped/transposed pack; output split over two destinations,
+    slot-wise accumulate mask on the first (the zero-copy concat gradient)."""
+    n, h, w, cin, cout = 2, 12, 20, 96, 32      # forward conv 96 -> 32; dgrad yields 96 = 64 (2 slots) + 32
+    g = torch.Generator().manual_seed(3)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    prev = torch.randn(n, 64, h, w, generator=g)
+    _, wd = pack(wt, dt)
+    dyb = nhwc(dy, dt)
+    gx = nhwc(prev, dt, pitch=160, off=0)        # level grad buffer, 5 slots of 32
+    gup = torch.zeros((n, h, w, 32), dtype=tdt(dt), device=DEV)
+    d = conv_desc(dt, n, h, w, dyb, cout, cout, wd, gx, 64, 160, dst1=gup, d1=32, q1=32, slot_w=32, mask=0b10)
+    L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "dgrad")
+    ref = F.conv_transpose2d(q(dy, dt).double(), q(wt, dt).double(), padding=1)
+    got0 = to_nchw(gx, 64)
+    exp0 = ref[:, :64].clone()
+    exp0[:, 32:64] += q(prev, dt)[:, 32:64].double()     # slot 1 accumulates, slot 0 overwrites
+    assert rel_err(got0, exp0) < TOL[dt]
+    assert rel_err(to_nchw(gup, 32), ref[:, 64:]) < TOL[dt]
+    assert float(gx[..., 64:].float().abs().max()) == 0.0      # other slots untouched
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
+@pytest.mark.parametrize("shape", [
+    (2, 20, 24, 32, 0, 32, 32),
+    (1, 16, 16, 64, 64, 64, 64),
+    (5, 6, 6, 64, 32, 64, 32),      # Cin = 96: ci tile straddles the two sources
+    (2, 8, 8, 32, 0, 32, 32),       # first-layer style: real Cin=3 padded to 32 handled by caller
+    (3, 1, 1, 32, 0, 64, 32),
+])
+def test_conv3x3_wgrad(dt, shape):
+    n, h, w, c0, c1, cout, _ = shape
+    g = torch.Generator().manual_seed(11)
+    cin = c0 + c1
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    s0 = nhwc(x[:, :c0], dt, pitch=c0 + 64)
+    s1 = nhwc(x[:, c0:], dt) if c1 else None
+    dyb = nhwc(dy, dt)
+    dw = torch.zeros(9 * cout * cin, dtype=torch.float32, device=DEV)
+    d = L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, c0 + 64, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(dw))
+    L.check(L.lib().nunet_conv3x3_wgrad(C.byref(d), L.stream()), "wgrad")
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(q(x, dt).double(), wt, padding=1).backward(q(dy, dt).double())
+    gout = torch.zeros(cout * cin * 9, dtype=torch.float32, device=DEV)
+    L.check(L.lib().nunet_unpack_wgrad(L.ptr(dw), cout, cin, cin, L.ptr(gout), 0, L.stream()), "unpack")
+    got = gout.view(cout, cin, 3, 3).cpu()
+    assert rel_err(got, wt.grad) < (5e-5 if dt == L.F32 else 1e-3), (DT[dt], shape)   # inputs are exact in T; only fp32 accumulation differs
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+def test_pack_unpack_roundtrip(dt):
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(64, 3, 3, 3, generator=g)
+    wf, _ = pack(w, dt, cin_pad=32, want_wd=False)
+    wf = wf.float().view(9, 64, 32).cpu()
+    ref = q(w, dt).permute(2, 3, 0, 1).reshape(9, 64, 3)
+    assert torch.equal(wf[:, :, :3], ref) and float(wf[:, :, 3:].abs().max()) == 0
+    w2 = torch.randn(32, 48, 3, 3, generator=g)
+    _, wd = pack(w2, dt)
+    wd = wd.float().view(9, 48, 32).cpu()
+    assert torch.equal(wd, q(w2, dt).flip(2, 3).permute(2, 3, 1, 0).reshape(9, 48, 32))
+    dw = torch.randn(9, 64, 32, generator=g)
+    gg = torch.ones(64 * 3 * 9, dtype=torch.float32, device=DEV)
+    L.check(L.lib().nunet_unpack_wgrad(L.ptr(dw.to(DEV)), 64, 3, 32, L.ptr(gg), 1, L.stream()), "unpack")
+    exp = dw[:, :, :3].permute(1, 2, 0).reshape(64, 3, 3, 3) + 1.0
+    np.testing.assert_allclose(gg.view(64, 3, 3, 3).cpu().numpy(), exp.numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_relu_fwd(dt, pool, training):
+    n, h, w, c = 3, 8, 12, 64
+    g = torch.Generator().manual_seed(2)
+    bias = torch.randn(c, generator=g) * 0.3
+    y = q(torch.randn(n, c, h, w, generator=g) * 0.7 + bias.view(1, -1, 1, 1), dt)
+    gamma = 1 + 0.2 * torch.randn(c, generator=g)
+    beta = 0.2 * torch.randn(c, generator=g)
+    rm = 0.1 * torch.randn(c, generator=g)
+    rv = 0.5 + torch.rand(c, generator=g)
+    yb = nhwc(y, dt)
+    dd = (y - bias.view(1, -1, 1, 1)).double()
+    stats = torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3))]).float().to(DEV)
+    a = torch.zeros((n, h, w, 160), dtype=tdt(dt), device=DEV)
+    pooled = torch.zeros((n, h // 2, w // 2, c), dtype=tdt(dt), device=DEV) if pool else None
+    rmg, rvg = rm.clone().to(DEV), rv.clone().to(DEV)
+    nbt = torch.tensor([4], dtype=torch.int64, device=DEV)
+    save = torch.zeros(2 * c, dtype=torch.float32, device=DEV)
+    d = L.BnFwdDesc(dt, n, h, w, c, L.ptr(yb), c, L.ptr(bias.to(DEV)), L.ptr(stats), L.ptr(gamma.to(DEV)), L.ptr(beta.to(DEV)),
+                    L.ptr(rmg), L.ptr(rvg), L.ptr(nbt), L.ptr(save), 1 if training else 0, 0.1, 1e-5,
+                    L.ptr(a, 32 * a.element_size()), 160, L.ptr(pooled), c)
+    L.check(L.lib().nunet_bn_relu_fwd(C.byref(d), L.stream()), "bn")
+    rm2, rv2 = rm.clone().double(), rv.clone().double()
+    ref = F.relu(F.batch_norm(y.double(), rm2, rv2, gamma.double(), beta.double(), training, 0.1, 1e-5))
+    got = to_nchw(a, c, off=32)
+    assert rel_err(got, ref) < TOL[dt]
+    assert float(a[..., :32].float().abs().max()) == 0 and float(a[..., 96:].float().abs().max()) == 0
+    if pool:
+        assert torch.equal(to_nchw(pooled, c), F.max_pool2d(got, 2, 2))
+    if training:
+        np.testing.assert_allclose(rmg.cpu().numpy(), rm2.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rvg.cpu().numpy(), rv2.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(nbt.item()) == 5
+        mean = y.double().mean((0, 2, 3))
+        var = y.double().var((0, 2, 3), unbiased=False)
+        np.testing.assert_allclose(save[:c].cpu().numpy(), mean.numpy(), atol=1e-5)
+        np.testing.assert_allclose(save[c:].cpu().numpy(), (1 / (var + 1e-5).sqrt()).numpy(), rtol=1e-4)
+    else:
+        assert torch.equal(rmg.cpu(), rm) and int(nbt.item()) == 4
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+def test_bn_relu_bwd(dt):
+    n, h, w, c = 3, 8, 12, 64
+    g = torch.Generator().manual_seed(4)
+    y = q(torch.randn(n, c, h, w, generator=g), dt)
+    da = q(torch.randn(n, c, h, w, generator=g), dt)
+    gamma = 1 + 0.2 * torch.randn(c, generator=g)
+    beta = 0.2 * torch.randn(c, generator=g)
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    out = F.relu(F.batch_norm(yd, None, None, gd, bd, True, 0.1, 1e-5))
+    out.backward(da.double())
+    mean = y.double().mean((0, 2, 3))
+    istd = 1 / (y.double().var((0, 2, 3), unbiased=False) + 1e-5).sqrt()
+    mi = torch.cat([mean, istd]).float().to(DEV)
+    yb = nhwc(y, dt)
+    dab = nhwc(da, dt, pitch=160, off=64)
+    sums = torch.zeros(2 * c, dtype=torch.float32, device=DEV)
+    dg = torch.zeros(c, dtype=torch.float32, device=DEV)
+    db = torch.zeros(c, dtype=torch.float32, device=DEV)
+    dbias = torch.zeros(c, dtype=torch.float32, device=DEV)
+    dyb = torch.zeros((n, h, w, c), dtype=tdt(dt), device=DEV)
+    d = L.BnBwdDesc(dt, n, h, w, c, L.ptr(dab, 64 * dab.element_size()), 160, L.ptr(yb), c, L.ptr(mi),
+                    L.ptr(gamma.to(DEV)), L.ptr(beta.to(DEV)), L.ptr(sums), L.ptr(dg), L.ptr(db), L.ptr(dbias),
+                    L.ptr(dyb), c)
+    L.check(L.lib().nunet_bn_relu_bwd_reduce(C.byref(d), L.stream()), "bn bwd reduce")
+    L.check(L.lib().nunet_bn_relu_bwd_apply(C.byref(d), L.stream()), "bn bwd apply")
+    assert rel_err(to_nchw(dyb, c), yd.grad) < TOL[dt]
+    assert rel_err(dg.cpu(), gd.grad) < 1e-4 and rel_err(db.cpu(), bd.grad) < 1e-4
+    # conv-bias gradient = sum of dy, analytically ~0; must be tiny relative to |dy| mass
+    assert float(dbias.abs().max()) < 2e-2 * float(yd.grad.abs().sum((0, 2, 3)).max())
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+def test_maxpool(dt):
+    n, h, w, c = 2, 8, 12, 32
+    g = torch.Generator().manual_seed(6)
+    x = q(torch.randn(n, c, h, w, generator=g), dt)
+    x[:, :, 0:2, 0:2] = 1.5            # ties: first maximum in scan order must win
+    dy = q(torch.randn(n, c, h // 2, w // 2, generator=g), dt)
+    prev = q(torch.randn(n, c, h, w, generator=g), dt)
+    xb = nhwc(x, dt, pitch=96, off=32)
+    yb = torch.zeros((n, h // 2, w // 2, c), dtype=tdt(dt), device=DEV)
+    es = xb.element_size()
+    L.check(L.lib().nunet_maxpool2x2_fwd(dt, n, h, w, c, L.ptr(xb, 32 * es), 96, L.ptr(yb), c, L.stream()), "pool")
+    xd = x.double().requires_grad_(True)
+    ref = F.max_pool2d(xd, 2, 2)
+    assert torch.equal(to_nchw(yb, c).double(), ref.detach())
+    ref.backward(dy.double())
+    for acc in (0, 1):
+        dxb = nhwc(prev, dt)
+        L.check(L.lib().nunet_maxpool2x2_bwd(dt, n, h, w, c, L.ptr(xb, 32 * es), 96, L.ptr(nhwc(dy, dt)), c,
+                                             L.ptr(dxb), c, acc, L.stream()), "pool bwd")
+        exp = xd.grad + (prev.double() if acc else 0)
+        assert rel_err(to_nchw(dxb, c), exp) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("hw", [(6, 10), (1, 1), (3, 2)])
+def test_upsample(dt, hw):
+    h, w = hw
+    n, c = 2, 64
+    g = torch.Generator().manual_seed(8)
+    x = q(torch.randn(n, c, h, w, generator=g), dt)
+    dy = q(torch.randn(n, c, 2 * h, 2 * w, generator=g), dt)
+    prev = q(torch.randn(n, c, h, w, generator=g), dt)
+    xb = nhwc(x, dt, pitch=128, off=64)
+    es = xb.element_size()
+    yb = torch.zeros((n, 2 * h, 2 * w, c), dtype=tdt(dt), device=DEV)
+    L.check(L.lib().nunet_upsample2x_fwd(dt, n, h, w, c, L.ptr(xb, 64 * es), 128, L.ptr(yb), c, L.stream()), "up")
+    xd = x.double().requires_grad_(True)
+    ref = F.interpolate(xd, scale_factor=2, mode="bilinear", align_corners=True)
+    assert rel_err(to_nchw(yb, c), ref.detach()) < TOL[dt]
+    ref.backward(dy.double())
+    for acc in (0, 1):
+        dxb = nhwc(prev, dt, pitch=128, off=64)
+        L.check(L.lib().nunet_upsample2x_bwd(dt, n, h, w, c, L.ptr(nhwc(dy, dt)), c, L.ptr(dxb, 64 * es), 128, acc,
+                                             L.stream()), "up bwd")
+        exp = xd.grad + (prev.double() if acc else 0)
+        assert rel_err(to_nchw(dxb, c, off=64), exp) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("k", [1, 4])
+def test_head(dt, k):
+    n, h, w, c = 2, 12, 20, 32
+    g = torch.Generator().manual_seed(9)
+    x = q(torch.randn(n, c, h, w, generator=g), dt)
+    wt = torch.randn(k, c, 1, 1, generator=g) * 0.2
+    b = torch.randn(k, generator=g) * 0.1
+    dl = torch.randn(n, k, h, w, generator=g)
+    xb = nhwc(x, dt, pitch=160, off=128)
+    es = xb.element_size()
+    logits = torch.zeros((n, k, h, w), dtype=torch.float32, device=DEV)
+    L.check(L.lib().nunet_head_fwd(dt, n, h, w, c, k, L.ptr(xb, 128 * es), 160, L.ptr(wt.to(DEV)), L.ptr(b.to(DEV)),
+                                   L.ptr(logits), L.stream()), "head")
+    xd = x.double().requires_grad_(True)
+    wd_, bd = wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xd, wd_, bd)
+    assert rel_err(logits.cpu(), ref.detach()) < 2e-5
+    ref.backward(dl.double())
+    dxb = torch.zeros((n, h, w, 160), dtype=tdt(dt), device=DEV)
+    dw = torch.zeros(k * c, dtype=torch.float32, device=DEV)
+    db = torch.zeros(k, dtype=torch.float32, device=DEV)
+    L.check(L.lib().nunet_head_bwd(dt, n, h, w, c, k, L.ptr(xb, 128 * es), 160, L.ptr(wt.to(DEV)), L.ptr(dl.to(DEV)),
+                                   L.ptr(dxb, 128 * es), 160, 0, L.ptr(dw), L.ptr(db), L.stream()), "head bwd")
+    assert rel_err(to_nchw(dxb, c, off=128), xd.grad) < TOL[dt]
+    assert rel_err(dw.view(k, c).cpu(), wd_.grad.view(k, c)) < 1e-4
+    assert rel_err(db.cpu(), bd.grad) < 1e-4
+
+
+def test_bce_dice_and_iou_against_reference_goldens():
+    from conftest import load_golden
+    g = load_golden("small_ops")
+    crit = nunet_amd.losses.BCEDiceLoss()
+    for tag in ("k1", "k4"):
+        x = torch.from_numpy(g["x_" + tag]).to(DEV).requires_grad_(True)
+        t = torch.from_numpy(g["t_" + tag]).to(DEV)
+        loss = crit(x, t)
+        (loss * 1.0).backward()
+        assert abs(float(loss) - float(g["loss_" + tag])) < 2e-6
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx_" + tag], atol=2e-9, rtol=2e-4)
+        assert abs(nunet_amd.metrics.iou_score(x, t) - float(g["iou_" + tag])) < 1e-12
+    # upstream gradient scaling (the /4 of deep supervision, reference trains.py:120-123)
+    x = torch.from_numpy(g["x_k1"]).to(DEV).requires_grad_(True)
+    (crit(x, torch.from_numpy(g["t_k1"]).to(DEV)) / 4).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx_k1"] / 4, atol=1e-9, rtol=2e-4)
+
+
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_sgd_matches_torch(nesterov):
+    g = torch.Generator().manual_seed(1)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=1e-3, momentum=0.9, weight_decay=1e-4, nesterov=nesterov)
+    p = p0.clone().to(DEV)
+    mom = torch.zeros(n, device=DEV)
+    lr = torch.tensor([1e-3], device=DEV)
+    for step in range(3):
+        gr = torch.randn(n, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        L.check(L.lib().nunet_sgd_step(L.ptr(p), L.ptr(gr.to(DEV)), L.ptr(mom), n, L.ptr(lr), 0.9, 1e-4,
+                                       1 if nesterov else 0, 1 if step == 0 else 0, 1.0, L.stream()), "sgd")
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_nchw_to_nhwc_pad():
+    x = torch.randn(2, 3, 5, 7)
+    y = torch.full((2, 5, 7, 32), 9.0, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib().nunet_nchw_to_nhwc(L.ptr(x.to(DEV)), 2, 3, 5, 7, L.BF16, L.ptr(y), 32, L.stream()), "layout")
+    assert torch.equal(y[..., :3].float().cpu(), x.permute(0, 2, 3, 1).bfloat16().float())
+    assert float(y[..., 3:].float().abs().max()) == 0
+
+
+def test_argument_errors_are_loud():
+    d = L.ConvDesc()
+    assert L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()) == -1
+    assert b"null" in L.lib().nunet_last_error()
+    with pytest.raises(L.NunetError):
+        nunet_amd.archs.NestedUNet(1)(torch.zeros(1, 3, 32, 32))          # CPU module: no fallback
+    m = nunet_amd.archs.NestedUNet(1).to(DEV)
+    with pytest.raises(L.NunetError):
+        m(torch.zeros(1, 3, 40, 40, device=DEV))                          # not a multiple of 16
