@@ -96,12 +96,12 @@ int nunet_unpack_wgrad(const float* dw, int32_t cout, int32_t cin, int32_t cin_p
 typedef struct {
   int32_t dtype;
   int32_t N, H, W, C;
-  const void* y; int32_t PY;        /* raw conv output */
-  const float* conv_bias;           /* [C]: stats are accumulated about the bias */
-  const float* stats;               /* [2][C] sums from nunet_conv3x3_fwd (training) */
+  const void* y; int32_t PY;        /* conv output stored WITHOUT its bias */
+  const float* conv_bias;           /* [C] or NULL: bias of the producing conv, folded in here */
+  const float* stats;               /* [2][C] sum / sum of squares of the stored y (training) */
   const float* gamma; const float* beta;
   float* running_mean; float* running_var; int64_t* num_batches_tracked;
-  float* save_mean_invstd;          /* [2][C] out (training) */
+  float* save_mean_invstd;          /* [2][C] out (training): mean of the stored y, 1/sqrt(var+eps) */
   int32_t training;
   float momentum, eps;
   void* a; int32_t PA;              /* relu(bn(y)) */

@@ -64,7 +64,8 @@ template <typename T> struct Vec16 {
   u32x4 raw;
   __device__ __forceinline__ float get(int i) const {
     if constexpr (std::is_same<T, float>::value) {
-      return __builtin_bit_cast(float, raw[i]);
+      const uint32_t w = raw[i];  // copy first: bit_cast of a vector-element lvalue reads element 0
+      return __builtin_bit_cast(float, w);
     } else {
       uint32_t w = raw[i >> 1];
       uint16_t hv = (i & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffff);
@@ -73,7 +74,8 @@ template <typename T> struct Vec16 {
   }
   __device__ __forceinline__ void set(int i, float v) {
     if constexpr (std::is_same<T, float>::value) {
-      raw[i] = __builtin_bit_cast(uint32_t, v);
+      const uint32_t w = __builtin_bit_cast(uint32_t, v);
+      raw[i] = w;
     } else {
       uint16_t hv = __builtin_bit_cast(uint16_t, (T)v);
       uint32_t w = raw[i >> 1];

@@ -68,13 +68,21 @@ struct BnFwdP {
   int N, H, W, C;
 };
 
-__device__ __forceinline__ void bn_channel_coeffs(const BnFwdP& p, int c, float M, float& mean, float& invstd, float& var) {
+// The 3x3 convs store their output WITHOUT the conv bias (it is absorbed here):
+// the first layers' outputs are bias-dominated (inputs are ~1e-2, reference
+// dataset.py:71), so a 16-bit store of acc+bias would lose the signal. With
+// y = acc + b:  train: bn(y) = gamma*(acc - mean(acc))*invstd + beta (bias cancels;
+// it only shifts running_mean);  eval: bn(y) = gamma*(acc - (rm - b))*invstd + beta.
+// `mean` is the value to subtract from the STORED tensor; `mean_full` = E[y].
+__device__ __forceinline__ void bn_channel_coeffs(const BnFwdP& p, int c, float M, float& mean, float& invstd, float& var, float& mean_full) {
+  const float b = p.conv_bias ? p.conv_bias[c] : 0.f;
   if (p.training) {
-    const float m0 = p.stats[c] / M;
-    var = fmaxf(p.stats[p.C + c] / M - m0 * m0, 0.f);
-    mean = m0 + (p.conv_bias ? p.conv_bias[c] : 0.f);
+    mean = p.stats[c] / M;
+    var = fmaxf(p.stats[p.C + c] / M - mean * mean, 0.f);
+    mean_full = mean + b;
   } else {
-    mean = p.rm[c];
+    mean_full = p.rm[c];
+    mean = mean_full - b;
     var = p.rv[c];
   }
   invstd = 1.0f / sqrtf(var + p.eps);
@@ -90,20 +98,20 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
 #pragma unroll
   for (int e = 0; e < EPV; ++e) {
     const int c = cg * EPV + e;
-    float mean, invstd, var;
-    bn_channel_coeffs(p, c, M, mean, invstd, var);
+    float mean, invstd, var, mf;
+    bn_channel_coeffs(p, c, M, mean, invstd, var, mf);
     sc[e] = p.gamma[c] * invstd;
     sh[e] = p.beta[c] - mean * sc[e];
   }
   if (blockIdx.x == 0 && p.training) {
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-      float mean, invstd, var;
-      bn_channel_coeffs(p, c, M, mean, invstd, var);
+      float mean, invstd, var, mf;
+      bn_channel_coeffs(p, c, M, mean, invstd, var, mf);
       p.save[c] = mean;
       p.save[p.C + c] = invstd;
       if (p.rm) {
         const float unb = M > 1.f ? var * (M / (M - 1.f)) : var;
-        p.rm[c] = (1.f - p.momentum) * p.rm[c] + p.momentum * mean;
+        p.rm[c] = (1.f - p.momentum) * p.rm[c] + p.momentum * mf;
         p.rv[c] = (1.f - p.momentum) * p.rv[c] + p.momentum * unb;
       }
     }

@@ -341,7 +341,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
         d.src1 = AB(arena, n.up); d.C1 = NBF[i + 1]; d.P1 = NBF[i + 1];
       }
       d.wpack = wpack + (size_t)L.wf * es;
-      d.bias = params + L.b_off;
+      d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
       d.dst0 = AB(arena, cv == 0 ? n.y1 : n.y2); d.D0 = f; d.Q0 = f;
       d.stats = training ? stats + L.stats : nullptr;
       CK(nunet_conv3x3_fwd(&d, s));

@@ -162,7 +162,8 @@ def test_pack_unpack_roundtrip(dt):
     assert torch.equal(wd, q(w2, dt).flip(2, 3).permute(2, 3, 1, 0).reshape(9, 48, 32))
     dw = torch.randn(9, 64, 32, generator=g)
     gg = torch.ones(64 * 3 * 9, dtype=torch.float32, device=DEV)
-    L.check(L.lib().nunet_unpack_wgrad(L.ptr(dw.to(DEV)), 64, 3, 32, L.ptr(gg), 1, L.stream()), "unpack")
+    dw_g = dw.to(DEV)
+    L.check(L.lib().nunet_unpack_wgrad(L.ptr(dw_g), 64, 3, 32, L.ptr(gg), 1, L.stream()), "unpack")
     exp = dw[:, :, :3].permute(1, 2, 0).reshape(64, 3, 3, 3) + 1.0
     np.testing.assert_allclose(gg.view(64, 3, 3, 3).cpu().numpy(), exp.numpy(), rtol=1e-6)
 
@@ -171,23 +172,26 @@ def test_pack_unpack_roundtrip(dt):
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_relu_fwd(dt, pool, training):
+    """The conv output is stored without its bias; BN folds the bias in analytically."""
     n, h, w, c = 3, 8, 12, 64
     g = torch.Generator().manual_seed(2)
     bias = torch.randn(c, generator=g) * 0.3
-    y = q(torch.randn(n, c, h, w, generator=g) * 0.7 + bias.view(1, -1, 1, 1), dt)
+    ys = q(torch.randn(n, c, h, w, generator=g) * 0.7, dt)          # stored tensor (acc, no bias)
+    y = ys + bias.view(1, -1, 1, 1)                                  # what the reference BN sees
     gamma = 1 + 0.2 * torch.randn(c, generator=g)
     beta = 0.2 * torch.randn(c, generator=g)
     rm = 0.1 * torch.randn(c, generator=g)
     rv = 0.5 + torch.rand(c, generator=g)
-    yb = nhwc(y, dt)
-    dd = (y - bias.view(1, -1, 1, 1)).double()
+    yb = nhwc(ys, dt)
+    dd = ys.double()
     stats = torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3))]).float().to(DEV)
     a = torch.zeros((n, h, w, 160), dtype=tdt(dt), device=DEV)
     pooled = torch.zeros((n, h // 2, w // 2, c), dtype=tdt(dt), device=DEV) if pool else None
     rmg, rvg = rm.clone().to(DEV), rv.clone().to(DEV)
     nbt = torch.tensor([4], dtype=torch.int64, device=DEV)
     save = torch.zeros(2 * c, dtype=torch.float32, device=DEV)
-    d = L.BnFwdDesc(dt, n, h, w, c, L.ptr(yb), c, L.ptr(bias.to(DEV)), L.ptr(stats), L.ptr(gamma.to(DEV)), L.ptr(beta.to(DEV)),
+    bias_g, gamma_g, beta_g = bias.to(DEV), gamma.to(DEV), beta.to(DEV)   # keep alive across the launch
+    d = L.BnFwdDesc(dt, n, h, w, c, L.ptr(yb), c, L.ptr(bias_g), L.ptr(stats), L.ptr(gamma_g), L.ptr(beta_g),
                     L.ptr(rmg), L.ptr(rvg), L.ptr(nbt), L.ptr(save), 1 if training else 0, 0.1, 1e-5,
                     L.ptr(a, 32 * a.element_size()), 160, L.ptr(pooled), c)
     L.check(L.lib().nunet_bn_relu_fwd(C.byref(d), L.stream()), "bn")
@@ -202,8 +206,8 @@ def test_bn_relu_fwd(dt, pool, training):
         np.testing.assert_allclose(rmg.cpu().numpy(), rm2.numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(rvg.cpu().numpy(), rv2.numpy(), rtol=1e-5, atol=1e-6)
         assert int(nbt.item()) == 5
-        mean = y.double().mean((0, 2, 3))
-        var = y.double().var((0, 2, 3), unbiased=False)
+        mean = ys.double().mean((0, 2, 3))
+        var = ys.double().var((0, 2, 3), unbiased=False)
         np.testing.assert_allclose(save[:c].cpu().numpy(), mean.numpy(), atol=1e-5)
         np.testing.assert_allclose(save[c:].cpu().numpy(), (1 / (var + 1e-5).sqrt()).numpy(), rtol=1e-4)
     else:
@@ -232,8 +236,9 @@ def test_bn_relu_bwd(dt):
     db = torch.zeros(c, dtype=torch.float32, device=DEV)
     dbias = torch.zeros(c, dtype=torch.float32, device=DEV)
     dyb = torch.zeros((n, h, w, c), dtype=tdt(dt), device=DEV)
+    gamma_g, beta_g = gamma.to(DEV), beta.to(DEV)
     d = L.BnBwdDesc(dt, n, h, w, c, L.ptr(dab, 64 * dab.element_size()), 160, L.ptr(yb), c, L.ptr(mi),
-                    L.ptr(gamma.to(DEV)), L.ptr(beta.to(DEV)), L.ptr(sums), L.ptr(dg), L.ptr(db), L.ptr(dbias),
+                    L.ptr(gamma_g), L.ptr(beta_g), L.ptr(sums), L.ptr(dg), L.ptr(db), L.ptr(dbias),
                     L.ptr(dyb), c)
     L.check(L.lib().nunet_bn_relu_bwd_reduce(C.byref(d), L.stream()), "bn bwd reduce")
     L.check(L.lib().nunet_bn_relu_bwd_apply(C.byref(d), L.stream()), "bn bwd apply")
@@ -261,7 +266,8 @@ def test_maxpool(dt):
     ref.backward(dy.double())
     for acc in (0, 1):
         dxb = nhwc(prev, dt)
-        L.check(L.lib().nunet_maxpool2x2_bwd(dt, n, h, w, c, L.ptr(xb, 32 * es), 96, L.ptr(nhwc(dy, dt)), c,
+        dyb = nhwc(dy, dt)
+        L.check(L.lib().nunet_maxpool2x2_bwd(dt, n, h, w, c, L.ptr(xb, 32 * es), 96, L.ptr(dyb), c,
                                              L.ptr(dxb), c, acc, L.stream()), "pool bwd")
         exp = xd.grad + (prev.double() if acc else 0)
         assert rel_err(to_nchw(dxb, c), exp) < TOL[dt]
@@ -286,7 +292,8 @@ def test_upsample(dt, hw):
     ref.backward(dy.double())
     for acc in (0, 1):
         dxb = nhwc(prev, dt, pitch=128, off=64)
-        L.check(L.lib().nunet_upsample2x_bwd(dt, n, h, w, c, L.ptr(nhwc(dy, dt)), c, L.ptr(dxb, 64 * es), 128, acc,
+        dyb = nhwc(dy, dt)
+        L.check(L.lib().nunet_upsample2x_bwd(dt, n, h, w, c, L.ptr(dyb), c, L.ptr(dxb, 64 * es), 128, acc,
                                              L.stream()), "up bwd")
         exp = xd.grad + (prev.double() if acc else 0)
         assert rel_err(to_nchw(dxb, c, off=64), exp) < TOL[dt]
@@ -304,7 +311,8 @@ def test_head(dt, k):
     xb = nhwc(x, dt, pitch=160, off=128)
     es = xb.element_size()
     logits = torch.zeros((n, k, h, w), dtype=torch.float32, device=DEV)
-    L.check(L.lib().nunet_head_fwd(dt, n, h, w, c, k, L.ptr(xb, 128 * es), 160, L.ptr(wt.to(DEV)), L.ptr(b.to(DEV)),
+    wt_g, b_g, dl_g = wt.to(DEV), b.to(DEV), dl.to(DEV)
+    L.check(L.lib().nunet_head_fwd(dt, n, h, w, c, k, L.ptr(xb, 128 * es), 160, L.ptr(wt_g), L.ptr(b_g),
                                    L.ptr(logits), L.stream()), "head")
     xd = x.double().requires_grad_(True)
     wd_, bd = wt.double().requires_grad_(True), b.double().requires_grad_(True)
@@ -314,7 +322,7 @@ def test_head(dt, k):
     dxb = torch.zeros((n, h, w, 160), dtype=tdt(dt), device=DEV)
     dw = torch.zeros(k * c, dtype=torch.float32, device=DEV)
     db = torch.zeros(k, dtype=torch.float32, device=DEV)
-    L.check(L.lib().nunet_head_bwd(dt, n, h, w, c, k, L.ptr(xb, 128 * es), 160, L.ptr(wt.to(DEV)), L.ptr(dl.to(DEV)),
+    L.check(L.lib().nunet_head_bwd(dt, n, h, w, c, k, L.ptr(xb, 128 * es), 160, L.ptr(wt_g), L.ptr(dl_g),
                                    L.ptr(dxb, 128 * es), 160, 0, L.ptr(dw), L.ptr(db), L.stream()), "head bwd")
     assert rel_err(to_nchw(dxb, c, off=128), xd.grad) < TOL[dt]
     assert rel_err(dw.view(k, c).cpu(), wd_.grad.view(k, c)) < 1e-4
@@ -353,7 +361,8 @@ def test_sgd_matches_torch(nesterov):
         gr = torch.randn(n, generator=g)
         ref.grad = gr.clone()
         opt.step()
-        L.check(L.lib().nunet_sgd_step(L.ptr(p), L.ptr(gr.to(DEV)), L.ptr(mom), n, L.ptr(lr), 0.9, 1e-4,
+        gr_g = gr.to(DEV)
+        L.check(L.lib().nunet_sgd_step(L.ptr(p), L.ptr(gr_g), L.ptr(mom), n, L.ptr(lr), 0.9, 1e-4,
                                        1 if nesterov else 0, 1 if step == 0 else 0, 1.0, L.stream()), "sgd")
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
 
@@ -361,7 +370,8 @@ def test_sgd_matches_torch(nesterov):
 def test_nchw_to_nhwc_pad():
     x = torch.randn(2, 3, 5, 7)
     y = torch.full((2, 5, 7, 32), 9.0, dtype=torch.bfloat16, device=DEV)
-    L.check(L.lib().nunet_nchw_to_nhwc(L.ptr(x.to(DEV)), 2, 3, 5, 7, L.BF16, L.ptr(y), 32, L.stream()), "layout")
+    x_g = x.to(DEV)
+    L.check(L.lib().nunet_nchw_to_nhwc(L.ptr(x_g), 2, 3, 5, 7, L.BF16, L.ptr(y), 32, L.stream()), "layout")
     assert torch.equal(y[..., :3].float().cpu(), x.permute(0, 2, 3, 1).bfloat16().float())
     assert float(y[..., 3:].float().abs().max()) == 0
 
