@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of one NestedUNet training step on MI355X.
+
+Workload (BASELINE.json configs[1]): NestedUNet(1, 3, deep_supervision=False), 96x96,
+per-GPU batch 16, bf16 storage / fp32 accumulate, BCEDiceLoss, SGD(lr 1e-3, mom 0.9,
+wd 1e-4). One "step" = the loop body of reference trains.py:113-135: forward, loss,
+IoU counts, backward, (gradient all-reduce for N>1), SGD — nothing skipped.
+Inputs are synthetic (pytorch_nested-unet_amd/synth.py) and resident in HBM before the
+timed region; each step copies the next staged batch into the graph's static inputs.
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     dominant kernel class, live hipEvent timing vs the MFMA / HBM roof
+  cpu_baseline the CPU oracle (oracle/nunet_oracle.py, kind "port") timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+TRAIN_GFLOP_PER_IMG_96 = 29.081
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--deep-supervision", action="store_true")
+    ap.add_argument("--num-classes", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, 16) = the GPU box's CPU share")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, budget_s):
+    """Reference CPU path: the oracle restatement (stock torch fp32 on the host cores),
+    same workload, bounded sample."""
+    import numpy as np
+    from oracle import nunet_oracle as O
+    import nunet_amd
+    synth = nunet_amd.synth
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = args.cpu_threads or min(cores, 16)
+    torch.set_num_threads(cores)
+    st = synth.closed_form_state(args.num_classes, 3, args.deep_supervision, True)
+    net = O.OracleNet(st, args.num_classes, 3, args.deep_supervision)
+    opt = O.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    img, msk = synth.synth_batch(args.batch, args.size, args.size, 3, args.num_classes, seed=1234)
+    x, t = torch.from_numpy(img), torch.from_numpy(msk)
+    O.train_step(net, opt, x, t)                       # warm-up (allocator, oneDNN primitives)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 20:
+        t0 = time.perf_counter()
+        O.train_step(net, opt, x, t)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": args.batch / med, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d steps of bs=%d %dx%d fp32 train step (oracle/nunet_oracle.py, torch CPU), median %.0f ms/step"
+                      % (len(times), args.batch, args.size, args.size, med * 1e3)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import nunet_amd
+    from nunet_amd import _lib as L
+    from nunet_amd.trainer import TrainStep
+    synth = nunet_amd.synth
+
+    torch.manual_seed(0)                                # identical replicas on every rank
+    model = nunet_amd.archs.NestedUNet(args.num_classes, 3, args.deep_supervision, dtype=args.dtype).to(dev)
+    model.train()
+    n, hw = args.batch, args.size
+    ts = TrainStep(model, (n, 3, hw, hw), lr=1e-3, momentum=0.9, weight_decay=1e-4,
+                   use_graph=not args.no_graph)
+    # pre-stage a small pool of synthetic batches in HBM (rank-distinct shards)
+    pool = []
+    for k in range(4):
+        img, msk = synth.synth_batch(n, hw, hw, 3, args.num_classes, seed=1234 + 100 * rank + k)
+        pool.append((torch.from_numpy(img).to(dev), torch.from_numpy(msk).to(dev)))
+    ts.capture(*pool[0])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        ts.step(*pool[k % len(pool)])
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ts.step(*pool[k % len(pool)])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss, iou = ts.epoch_stats()
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n * args.steps / dt
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # live per-kernel timing: the same step, eager, hipEvents around every launch
+        for _ in range(2):
+            ts._fwd_bwd(); ts._allreduce(); ts._opt()
+        torch.cuda.synchronize()
+        reps = max(3, min(10, args.steps))
+        L.profile_begin()
+        for _ in range(reps):
+            ts._fwd_bwd()
+            ts._opt()
+        torch.cuda.synchronize()
+        prof = L.profile_end()
+        tot = sum(e["ms"] for e in prof)
+        prof.sort(key=lambda e: -e["ms"])
+        top = prof[0]
+        avg_ms = top["ms"] / top["launches"]
+        tflops = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
+        gbs = top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9
+        mfma_bound = top["flops"] > 0 and (top["flops"] / (PEAK[args.dtype] * 1e12)) >= (top["bytes"] / (HBM_PEAK_GBS * 1e9))
+        if mfma_bound:
+            roofline = {"bound": "mfma", "achieved": tflops, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                        "frac": tflops / PEAK[args.dtype], "traffic": None}
+        else:
+            roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": None}
+        roofline["kernel"] = top["name"]
+        roofline["avg_launch_us"] = avg_ms * 1e3
+        roofline["launches_per_step"] = top["launches"] / reps
+        roofline["share_of_kernel_time"] = top["ms"] / tot
+        roofline["classes"] = [{"name": e["name"], "launches_per_step": e["launches"] / reps,
+                                "us_per_step": e["ms"] * 1e3 / reps,
+                                "tflops": (e["flops"] / (e["ms"] * 1e-3) / 1e12) if e["ms"] > 0 else 0.0,
+                                "gbs": (e["bytes"] / (e["ms"] * 1e-3) / 1e9) if e["ms"] > 0 else 0.0} for e in prof]
+        if hw == 96:
+            step_tflops = TRAIN_GFLOP_PER_IMG_96 * n / 1e3 / (ms_per_step * 1e-3)
+            roofline["whole_step_tflops"] = step_tflops
+            roofline["whole_step_frac_of_mfma_peak"] = step_tflops / PEAK[args.dtype]
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec NestedUNet 96x96 bs=16 train" if hw == 96 and n == 16 else
+                      "images/sec NestedUNet %dx%d bs=%d train" % (hw, hw, n),
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "NestedUNet(num_classes=%d, in=3, deep_supervision=%s) %dx%d per-GPU batch %d, "
+                                   "%s storage / fp32 accumulate, BCEDiceLoss, SGD(1e-3, 0.9, wd 1e-4), "
+                                   "fwd+loss+iou+bwd%s+sgd per step (BASELINE.json configs[%d])"
+                                   % (args.num_classes, args.deep_supervision, hw, hw, n, args.dtype,
+                                      "+allreduce" if world > 1 else "", 2 if args.deep_supervision else 1),
+                       "global_batch": world * n, "parallelism": "dp%d" % world, "hip_graph": not args.no_graph},
+            "final_loss": loss, "final_iou": iou,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,6 +219,20 @@ int nunet_plan_backward(nunet_plan* p, const float* params, const float* dlogits
 int64_t nunet_plan_feature(const nunet_plan* p, int32_t i, int32_t j, int32_t* pitch,
                            int32_t* channels);
 
+/* ------------------------------------------------------------------------ */
+/* Measurement aid (bench.py roofline leg): hipEvent timing of every launch    */
+/* issued by this thread between begin and end, aggregated per kernel class.   */
+/* profile_end() waits for the events (the only host-synchronising entry).     */
+/* flops/bytes are the ALGORITHMIC figures of the launches.        */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  char name[48];
+  int32_t launches;
+  double ms, flops, bytes;
+} nunet_prof_entry;
+int nunet_profile_begin(void);
+int nunet_profile_end(nunet_prof_entry* out, int32_t max_entries, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

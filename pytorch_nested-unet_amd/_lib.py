@@ -58,6 +58,11 @@ class BnBwdDesc(C.Structure):
                 ("dy", _vp), ("PDY", _i32)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", _i32), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class PlanCfg(C.Structure):
     _fields_ = [("N", _i32), ("H", _i32), ("W", _i32),
                 ("input_channels", _i32), ("num_classes", _i32), ("deep_supervision", _i32),
@@ -97,6 +102,8 @@ _SIG = {
     "nunet_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "nunet_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "nunet_plan_feature": (_i64, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "nunet_profile_begin": (_i32, []),
+    "nunet_profile_end": (_i32, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
 }
 
 _lib = None
@@ -131,6 +138,19 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def profile_begin():
+    check(lib().nunet_profile_begin(), "nunet_profile_begin")
+
+
+def profile_end():
+    """[{name, launches, ms, flops, bytes}] per kernel class; synchronises with the device."""
+    arr = (ProfEntry * 32)()
+    n = _i32(0)
+    check(lib().nunet_profile_end(arr, 32, C.byref(n)), "nunet_profile_end")
+    return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
+                 bytes=arr[i].bytes) for i in range(n.value) if arr[i].launches]
 
 
 def check(rc, what=""):

@@ -34,6 +34,30 @@ int nunet_check_launch(const char* what);
     }                                       \
   } while (0)
 
+// ---------------------------------------------------------------------------
+// optional per-launch timing (bench.py's roofline leg): hipEvents on the launch
+// stream around every kernel, aggregated per kernel class. Off by default.
+// ---------------------------------------------------------------------------
+enum {
+  PC_CONV_M256N32 = 0, PC_CONV_M128N64, PC_WGRAD_1x4, PC_WGRAD_2x2, PC_BN_FWD, PC_BN_BWD_REDUCE,
+  PC_BN_BWD_APPLY, PC_UP_FWD, PC_UP_BWD, PC_POOL, PC_HEAD, PC_PACK, PC_UNPACK, PC_LOSS, PC_SGD,
+  PC_LAYOUT, PC_COUNT
+};
+extern thread_local bool g_prof_on;
+extern thread_local int g_prof_alg_cin;  // >0: algorithmic Cin of the next conv/wgrad (padded first layer)
+void nunet_prof_push(int cls, double flops, double bytes, hipStream_t st);
+void nunet_prof_pop(hipStream_t st);
+struct ProfScope {
+  hipStream_t st; bool on;
+  ProfScope(int cls, double flops, double bytes, hipStream_t s) : st(s), on(g_prof_on) { if (on) nunet_prof_push(cls, flops, bytes, s); }
+  ~ProfScope() { if (on) nunet_prof_pop(st); }
+};
+
+// zero-fill by a kernel on the caller's stream. hipMemsetAsync is NOT used anywhere:
+// captured into a hipGraph its memset node ran unordered w.r.t. the neighbouring kernel
+// nodes on replay (accumulators were cleared late / early), see DESIGN.md.
+int nunet_zero_async(void* p, size_t bytes, hipStream_t st);
+
 static inline int dtype_size(int dt) { return dt == NUNET_F32 ? 4 : 2; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -305,6 +305,10 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG;
   p.nCoT = p.Cout / C::BN;
   const long grid = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
+  const double px = (double)d->N * d->H * d->W;
+  const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
+  ProfScope ps(C::BN == 32 ? PC_CONV_M256N32 : PC_CONV_M128N64, 2.0 * 9 * acin * p.Cout * px,
+               (px * (acin + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
   hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   return nunet_check_launch("conv3x3");
 }
@@ -511,6 +515,10 @@ static int launch_wgrad_cfg(const nunet_wgrad_desc* d, hipStream_t st) {
   if (ks < 1) ks = 1;
   p.ksplit = ks;
   const long grid = (long)otiles * ks;
+  const double px = (double)d->N * d->H * d->W;
+  const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
+  ProfScope ps(WCO == 1 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, 2.0 * 9 * acin * p.Cout * px,
+               px * (acin + p.Cout) * sizeof(T) + 9.0 * acin * p.Cout * 4, st);
   hipLaunchKernelGGL((wgrad_kernel<T, WCO, WCI>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   return nunet_check_launch("wgrad3x3");
 }

@@ -31,6 +31,20 @@ static inline int grid_for(int64_t items, int block, int cap = 256 * 16) {
   return (int)g;
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(u32x4* __restrict__ p16, size_t n16, uint32_t* __restrict__ tail, int ntail) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p16[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0u;
+}
+int nunet_zero_async(void* p, size_t bytes, hipStream_t st) {
+  NUNET_REQUIRE(((uintptr_t)p % 16) == 0 && bytes % 4 == 0, "zero: buffer must be 16-byte aligned, size a multiple of 4");
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)((bytes % 16) / 4);
+  hipLaunchKernelGGL(zero_kernel, dim3(grid_for((int64_t)n16, 256 * 4, 2048)), dim3(256), 0, st, (u32x4*)p, n16,
+                     (uint32_t*)((char*)p + n16 * 16), ntail);
+  return nunet_check_launch("zero");
+}
+
 // ---------------------------------------------------------------------------
 // layout: NCHW fp32 -> NHWC T with zero channel padding
 // ---------------------------------------------------------------------------
@@ -48,6 +62,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, i
 }
 template <typename T> static int launch_nchw_to_nhwc(const float* x, int N, int C, int H, int W, void* y, int cpad, hipStream_t st) {
   const int64_t total = (int64_t)N * H * W * cpad;
+  ProfScope ps(PC_LAYOUT, 0, (double)total * sizeof(T) + (double)N * C * H * W * 4, st);
   hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, x, N, C, H, W, (T*)y, cpad);
   return nunet_check_launch("nchw_to_nhwc");
 }
@@ -169,6 +184,7 @@ template <typename T> static int launch_bn_fwd(const nunet_bn_fwd_desc* d, hipSt
   p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C;
   const int G = d->C / Tr<T>::EPV;
   const int ppb = 256 / G;
+  ProfScope ps(PC_BN_FWD, 0, (double)d->N * d->H * d->W * d->C * sizeof(T) * (d->pooled ? 2.25 : 2.0), st);
   if (d->pooled) {
     const int64_t nq = (int64_t)d->N * (d->H / 2) * (d->W / 2);
     hipLaunchKernelGGL((bn_relu_fwd_kernel<T, true>), dim3(grid_for(nq, ppb)), dim3(256), 0, st, p);
@@ -278,6 +294,7 @@ template <typename T, bool APPLY> static int launch_bn_bwd_t(const nunet_bn_bwd_
   const int G = d->C / Tr<T>::EPV;
   const int64_t np = (int64_t)d->N * d->H * d->W;
   // fewer, fatter blocks: each block ends with 2C global atomics
+  ProfScope ps(APPLY ? PC_BN_BWD_APPLY : PC_BN_BWD_REDUCE, 0, (double)np * d->C * sizeof(T) * (APPLY ? 3.0 : 2.0), st);
   hipLaunchKernelGGL((bn_relu_bwd_kernel<T, APPLY>), dim3(grid_for(np, (256 / G) * 8, 1024)), dim3(256), 0, st, p);
   return nunet_check_launch(APPLY ? "bn_relu_bwd_apply" : "bn_relu_bwd_reduce");
 }
@@ -374,11 +391,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 }
 template <typename T> static int launch_maxpool_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
+  ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * 1.25, st);
   hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C);
   return nunet_check_launch("maxpool_fwd");
 }
 template <typename T> static int launch_maxpool_bwd(int N, int H, int W, int C, const void* x, int PX, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
+  ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * (acc ? 3.25 : 2.25), st);
   hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C);
   return nunet_check_launch("maxpool_bwd");
 }
@@ -484,11 +503,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 }
 template <typename T> static int launch_up_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * 4 * H * W * (C / Tr<T>::EPV);
+  ProfScope ps(PC_UP_FWD, 0, (double)N * H * W * C * sizeof(T) * 5.0, st);
   hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C);
   return nunet_check_launch("upsample_fwd");
 }
 template <typename T> static int launch_up_bwd(int N, int H, int W, int C, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
   const int64_t total = (int64_t)N * H * W * (C / Tr<T>::EPV);
+  ProfScope ps(PC_UP_BWD, 0, (double)N * H * W * C * sizeof(T) * (acc ? 6.0 : 5.0), st);
   hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C);
   return nunet_check_launch("upsample_bwd");
 }
@@ -573,10 +594,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   }
 }
 template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* b, float* logits, hipStream_t st) {
+  ProfScope ps(PC_HEAD, 2.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) + K * 4), st);
   hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 256)), dim3(256), 0, st, (const T*)x, PX, w, b, logits, N, H, W, C, K);
   return nunet_check_launch("head_fwd");
 }
 template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw, float* db, hipStream_t st) {
+  ProfScope ps(PC_HEAD, 4.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) * (acc ? 3 : 2) + K * 4), st);
   hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 8 * 16, 1024)), dim3(256), 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw, db, N, H, W, C, K);
   return nunet_check_launch("head_bwd");
 }
@@ -651,8 +674,9 @@ extern "C" size_t nunet_bce_dice_ws_bytes(int32_t N) { return (size_t)(3 * N + 1
 extern "C" int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int64_t per, float* ws, float* loss, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && loss && N > 0 && per > 0, "bce_dice_fwd: bad args");
   hipStream_t st = (hipStream_t)s;
-  if (hipMemsetAsync(ws, 0, nunet_bce_dice_ws_bytes(N), st) != hipSuccess) { nunet_set_error("bce_dice_fwd: memset failed"); return NUNET_ELAUNCH; }
+  { int rc = nunet_zero_async(ws, nunet_bce_dice_ws_bytes(N), st); if (rc) return rc; }
   const int gx = grid_for(per, 256 * 4, 64);
+  ProfScope ps(PC_LOSS, 0, (double)N * per * 8, st);
   hipLaunchKernelGGL(bce_dice_partial_kernel, dim3(gx, N), dim3(256), 0, st, logits, target, per, ws, N);
   hipLaunchKernelGGL(bce_dice_final_kernel, dim3(1), dim3(64), 0, st, ws, N, per, loss);
   return nunet_check_launch("bce_dice_fwd");
@@ -660,6 +684,7 @@ extern "C" int nunet_bce_dice_fwd(const float* logits, const float* target, int3
 extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per, const float* ws, const float* gscale, float* dlogits, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && dlogits && N > 0 && per > 0, "bce_dice_bwd: bad args");
   const int gx = grid_for(per, 256 * 4, 64);
+  ProfScope ps(PC_LOSS, 0, (double)N * per * 12, (hipStream_t)s);
   hipLaunchKernelGGL(bce_dice_bwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)s, logits, target, per, ws, gscale, dlogits, N);
   return nunet_check_launch("bce_dice_bwd");
 }
@@ -683,6 +708,7 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict
 }
 extern "C" int nunet_iou_counts(const float* logits, const float* target, int64_t n, unsigned long long* counts, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && counts && n > 0, "iou_counts: bad args");
+  ProfScope ps(PC_LOSS, 0, (double)n * 8, (hipStream_t)s);
   hipLaunchKernelGGL(iou_counts_kernel, dim3(grid_for(n, 256 * 4, 256)), dim3(256), 0, (hipStream_t)s, logits, target, n, counts);
   return nunet_check_launch("iou_counts");
 }
@@ -705,6 +731,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 }
 extern "C" int nunet_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* lr_dev, float momentum, float weight_decay, int32_t nesterov, int32_t first, float grad_scale, nunet_stream_t s) {
   NUNET_REQUIRE(p && g && lr_dev && n > 0 && (momentum == 0.f || mom), "sgd_step: bad args");
+  ProfScope ps(PC_SGD, 0, (double)n * 20, (hipStream_t)s);
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, (hipStream_t)s, p, g, mom, n, lr_dev, momentum, weight_decay, nesterov, first, grad_scale);
   return nunet_check_launch("sgd_step");
 }

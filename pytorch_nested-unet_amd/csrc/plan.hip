@@ -74,6 +74,9 @@ template <typename T> static int launch_pack(const float* params, void* arena_t,
   int gx = (int)ceil_div64(maxn, 256 * 4);
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
+  double pb = 0;
+  for (int i = 0; i < tab.n; ++i) pb += 9.0 * tab.e[i].cout * tab.e[i].cin * (4 + (tab.e[i].wd >= 0 ? 2 : 1) * sizeof(T));
+  ProfScope ps(PC_PACK, 0, pb, st);
   hipLaunchKernelGGL((pack_kernel<T>), dim3(gx, tab.n), dim3(256), 0, st, params, (T*)arena_t, tab);
   return nunet_check_launch("pack_weights");
 }
@@ -314,7 +317,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
   if (training) {
-    if (hipMemsetAsync(stats, 0, P->stats_floats * 4, st) != hipSuccess) { nunet_set_error("plan_forward: memset failed"); return NUNET_ELAUNCH; }
+    CK(nunet_zero_async(stats, P->stats_floats * 4, st));
   }
   if (dt == NUNET_F32) CK(launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, st));
   else if (dt == NUNET_BF16) CK(launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, st));
@@ -344,7 +347,10 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
       d.dst0 = AB(arena, cv == 0 ? n.y1 : n.y2); d.D0 = f; d.Q0 = f;
       d.stats = training ? stats + L.stats : nullptr;
-      CK(nunet_conv3x3_fwd(&d, s));
+      g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
+      const int rc_conv = nunet_conv3x3_fwd(&d, s);
+      g_prof_alg_cin = 0;
+      CK(rc_conv);
 
       nunet_bn_fwd_desc b; memset(&b, 0, sizeof(b));
       b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
@@ -380,7 +386,7 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
   float* bsums = gsr + (P->gs_floats - P->stats_floats);
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
-  if (hipMemsetAsync(gsr, 0, P->gs_floats * 4, st) != hipSuccess) { nunet_set_error("plan_backward: memset failed"); return NUNET_ELAUNCH; }
+  CK(nunet_zero_async(gsr, P->gs_floats * 4, st));
   bool written[5][5]; memset(written, 0, sizeof(written));
 
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
@@ -422,7 +428,10 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
         w.src1 = AB(arena, n.up); w.C1 = NBF[i + 1]; w.P1 = NBF[i + 1];
       }
       w.dy = b.dy; w.Cout = f; w.PY = f; w.dw = gsr + L.gs;
-      CK(nunet_conv3x3_wgrad(&w, s));
+      g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
+      const int rc_wg = nunet_conv3x3_wgrad(&w, s);
+      g_prof_alg_cin = 0;
+      CK(rc_wg);
       // dgrad
       if (cv == 0 && i == 0 && n.in_prefix == 0) continue;  // no gradient into the image
       nunet_conv_desc d; memset(&d, 0, sizeof(d));
@@ -455,6 +464,7 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
   P->utab.accumulate = accumulate;
   int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
   if (gx > 512) gx = 512;
+  ProfScope ps(PC_UNPACK, 0, (double)P->nparams * (accumulate ? 12 : 8), st);
   hipLaunchKernelGGL(unpack_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, gsr, grads, P->utab);
   return nunet_check_launch("unpack_grads");
 }

@@ -1,0 +1,61 @@
+// prof.hip — per-launch hipEvent timing aggregated per kernel class (see common.h).
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+thread_local bool g_prof_on = false;
+thread_local int g_prof_alg_cin = 0;
+
+struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
+static thread_local std::vector<ProfRec> g_recs;
+static thread_local std::vector<hipEvent_t> g_pool;
+static thread_local size_t g_pool_used = 0;
+
+static hipEvent_t get_event() {
+  if (g_pool_used == g_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    g_pool.push_back(e);
+  }
+  return g_pool[g_pool_used++];
+}
+void nunet_prof_push(int cls, double flops, double bytes, hipStream_t st) {
+  ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.e0 = get_event(); r.e1 = get_event();
+  (void)hipEventRecord(r.e0, st);
+  g_recs.push_back(r);
+}
+void nunet_prof_pop(hipStream_t st) { (void)hipEventRecord(g_recs.back().e1, st); }
+
+static const char* kNames[PC_COUNT] = {
+    "conv3x3_fwd_dgrad<BM256,BN32>", "conv3x3_fwd_dgrad<BM128,BN64>", "conv3x3_wgrad<1x4>", "conv3x3_wgrad<2x2>",
+    "bn_relu_fwd(+pool)", "bn_relu_bwd_reduce", "bn_relu_bwd_apply", "upsample2x_fwd", "upsample2x_bwd",
+    "maxpool2x2", "head_1x1", "pack_weights", "unpack_grads", "bce_dice+iou", "sgd_step", "layout"};
+
+extern "C" int nunet_profile_begin(void) {
+  g_recs.clear();
+  g_pool_used = 0;
+  g_prof_on = true;
+  return NUNET_OK;
+}
+// Host-synchronising by design: waits for the recorded events, then aggregates.
+extern "C" int nunet_profile_end(nunet_prof_entry* out, int32_t max_entries, int32_t* n_out) {
+  g_prof_on = false;
+  NUNET_REQUIRE(out && n_out && max_entries >= PC_COUNT, "profile_end: need room for %d entries", PC_COUNT);
+  for (int c = 0; c < PC_COUNT; ++c) {
+    memset(&out[c], 0, sizeof(out[c]));
+    strncpy(out[c].name, kNames[c], sizeof(out[c].name) - 1);
+  }
+  for (size_t i = 0; i < g_recs.size(); ++i) {
+    const ProfRec& r = g_recs[i];
+    if (hipEventSynchronize(r.e1) != hipSuccess) { nunet_set_error("profile_end: event sync failed"); return NUNET_ELAUNCH; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes;
+  }
+  *n_out = PC_COUNT;
+  g_recs.clear();
+  g_pool_used = 0;
+  return NUNET_OK;
+}

@@ -257,9 +257,42 @@ def test_grad_accumulation_and_zero_grad_semantics(synth):
     crit(m(x.to(DEV)), t.to(DEV)).backward()
     named = [(k, p) for k, p in m.named_parameters() if not (k.endswith("conv1.bias") or k.endswith("conv2.bias"))]
     g1 = {k: a for (k, _), a in zip(m.named_parameters(), g1)}
+
+    def close(a, b):      # semantics check (x1 vs x2), robust to atomic-order noise on an ill-conditioned gradient
+        return float((a - b).norm()) <= 0.05 * float(b.norm()) + 1e-8
+
     for k, p in named:      # conv biases before BN have pure-noise gradients: skipped
-        assert float((p.grad - 2 * g1[k]).abs().max()) <= 2e-2 * float(g1[k].abs().max()) + 1e-8, k
+        assert close(p.grad, 2 * g1[k]), k
     m.zero_grad(set_to_none=False)
     crit(m(x.to(DEV)), t.to(DEV)).backward()
     for k, p in named:
-        assert float((p.grad - g1[k]).abs().max()) <= 2e-2 * float(g1[k].abs().max()) + 1e-8, k
+        assert close(p.grad, g1[k]), k
+
+def test_fused_train_step_graph_matches_eager_and_oracle(synth):
+    """TrainStep (trainer.py): the hipGraph-captured step must follow the same trajectory
+    as the eager step and as the CPU oracle loop (reference trains.py:113-135)."""
+    from nunet_amd.trainer import TrainStep
+    n, hw = 4, 32
+    st = synth.closed_form_state(1, 3, False, True)
+    batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=1234 + k) for k in range(3)]
+    net = O.OracleNet(st, 1, 3, False)
+    opt = O.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    ref = [O.train_step(net, opt, torch.from_numpy(b[0]), torch.from_numpy(b[1])) for b in batches]
+    for graph in (False, True):
+        m = nunet_amd.archs.NestedUNet(1, 3, False)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
+        m = m.to(DEV).train()
+        ts = TrainStep(m, (n, 3, hw, hw), use_graph=graph)
+        if graph:
+            ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+        for k, b in enumerate(batches):
+            ts.reset_meters()
+            ts.step(torch.from_numpy(b[0]).to(DEV), torch.from_numpy(b[1]).to(DEV))
+            loss, iou = ts.epoch_stats()
+            assert abs(loss - ref[k][0]) < (1e-4 if k == 0 else 3e-3), (graph, k, loss, ref[k][0])
+            assert abs(iou - ref[k][1]) < 2e-2, (graph, k, iou, ref[k][1])
+        assert bool(torch.isfinite(ts.eng.flat_params).all())
+        # parameters after 3 steps agree with the oracle's (momentum + weight decay path)
+        w = m.conv0_4.conv2.weight.detach().cpu()
+        rw = net.params["conv0_4.conv2.weight"].detach()
+        assert float((w - rw).abs().max()) < 2e-5
