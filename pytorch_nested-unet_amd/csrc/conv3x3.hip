@@ -11,6 +11,8 @@
 //                 gfx950 transposing LDS read (ds_read_b64_tr_b16) for 16-bit types.
 //
 // MFMA shapes: 32x32x16 (bf16 / f16) and 32x32x2 (f32, exact fp32).
+#include <stdlib.h>
+
 #include "common.h"
 
 // ---------------------------------------------------------------------------
@@ -65,7 +67,7 @@ struct ConvP {
   int slot_w; unsigned acc0_mask; int acc1;
   float* stats;
   int N, H, W, Cin, Cout;
-  int NI, TH, TW, tilesX, tilesY, tilesG, nCoT;
+  int NI, TH, TW, tilesX, tilesY, tilesG, nCoT, nItems;
 };
 
 template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
@@ -75,35 +77,41 @@ template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
   static constexpr int BN = 32 * SN * WN;
   static constexpr int EPV = Tr<T>::EPV;
   static constexpr int KC = 64 / (int)sizeof(T);  // channels per LDS chunk (64 B per pixel)
+  static constexpr int KS = KC / 16;              // MFMA k-steps per tap per chunk
   static constexpr int PS = KC + EPV;             // padded pixel stride (80 B)
   static constexpr int HPMAX = BM + BM / 2;       // halo pixel capacity
   static constexpr int UH = (HPMAX * 4 + NT - 1) / NT;
   static constexpr int UW = (9 * BN * 4 + NT - 1) / NT;
+  static constexpr int OS = BN + EPV;             // epilogue staging row stride (elements)
+  static constexpr int UO = (BM * (BN / EPV) + NT - 1) / NT;
+  static constexpr int HALO_ELEMS = HPMAX * PS;
+  static constexpr int W_ELEMS = 9 * BN * PS;
+  static constexpr int STAGE_ELEMS = (HALO_ELEMS + W_ELEMS) > BM * OS ? (HALO_ELEMS + W_ELEMS) : BM * OS;
 };
 
+// Persistent kernel: each workgroup walks (tile, Cout-tile) items with stride gridDim.x.
+// The global loads of the NEXT (item, channel chunk) are issued into registers before the
+// current chunk's MFMA sweep, so HBM latency hides under compute and under the previous
+// tile's epilogue, and co-resident workgroups de-synchronise their load/compute/store phases.
 template <typename T, int WM, int WN, int SM, int SN>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
   typedef Mma<T> M;
-  constexpr int PS = C::PS, EPV = C::EPV, BN = C::BN, BM = C::BM, NT = C::NT;
+  constexpr int PS = C::PS, EPV = C::EPV, BN = C::BN, BM = C::BM, NT = C::NT, KS = C::KS, OS = C::OS;
 
-  __shared__ __attribute__((aligned(16))) T s_halo[C::HPMAX * PS];
-  __shared__ __attribute__((aligned(16))) T s_w[9 * BN * PS];
-  __shared__ int s_hidx[BM];
-  __shared__ int s_gpix[BM];
+  // one LDS arena: [halo | weights] during the K loop, [BM][OS] output staging in the epilogue
+  __shared__ __attribute__((aligned(16))) T s_buf[C::STAGE_ELEMS];
+  __shared__ int s_hidx[BM];         // tile-invariant: halo index of output row m
+  __shared__ int s_mxy[BM];          // tile-invariant: packed (ni, ly, lx) of row m, -1 unused
+  __shared__ int s_hxy[C::HPMAX];    // tile-invariant: packed (ni, hy, hx) of halo pixel, -1 unused
+  __shared__ int s_gpix[BM];         // per item: global pixel of row m, -1 masked
   __shared__ float s_red[2 * WM * BN];
+  T* const s_halo = s_buf;
+  T* const s_w = s_buf + C::HALO_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
-
-  int bid = blockIdx.x;
-  const int cot = bid % p.nCoT; bid /= p.nCoT;
-  const int tx = bid % p.tilesX; bid /= p.tilesX;
-  const int ty = bid % p.tilesY;
-  const int tg = bid / p.tilesY;
-  const int x0 = tx * p.TW, y0 = ty * p.TH, n0 = tg * p.NI;
-  const int co0 = cot * BN;
   const int HW2 = p.TW + 2, HH2 = p.TH + 2;
   const int HP = p.NI * HH2 * HW2;
   const int THW = p.TH * p.TW;
@@ -112,33 +120,63 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
     const int ni = m / THW;
     const int rem = m - ni * THW;
     const int ly = rem / p.TW, lx = rem - ly * p.TW;
-    const int n = n0 + ni, y = y0 + ly, x = x0 + lx;
-    const bool ok = ni < p.NI && n < p.N && y < p.H && x < p.W;
+    const bool ok = ni < p.NI;
     s_hidx[m] = ok ? ((ni * HH2 + ly + 1) * HW2 + lx + 1) : (HW2 + 1);
-    s_gpix[m] = ok ? ((n * p.H + y) * p.W + x) : -1;
+    s_mxy[m] = ok ? ((ni << 20) | (ly << 10) | lx) : -1;
   }
-
-  // per-thread staging units (fixed across channel chunks)
-  int hgp[C::UH];
-#pragma unroll
-  for (int k = 0; k < C::UH; ++k) {
-    const int u = tid + k * NT;
-    const int hp = u >> 2;
-    int gp = -2;
+  for (int hp = tid; hp < C::HPMAX; hp += NT) {
+    int code = -1;
     if (hp < HP) {
       const int ni = hp / (HH2 * HW2);
       const int rem = hp - ni * (HH2 * HW2);
       const int hy = rem / HW2, hx = rem - hy * HW2;
-      const int n = n0 + ni, y = y0 + hy - 1, x = x0 + hx - 1;
-      gp = (n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W) ? ((n * p.H + y) * p.W + x) : -1;
+      code = (ni << 20) | (hy << 10) | hx;
     }
-    hgp[k] = gp;
+    s_hxy[hp] = code;
   }
+  __syncthreads();
+
+  int abase[SM];
+#pragma unroll
+  for (int a = 0; a < SM; ++a) abase[a] = s_hidx[(wm * SM + a) * 32 + r] * PS + 8 * h;
+  int toff[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) toff[tap] = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PS;
+  const int bbase = ((wn * SN) * 32 + r) * PS + 8 * h;
+  int hcode[C::UH];
+#pragma unroll
+  for (int k = 0; k < C::UH; ++k) {
+    const int hp = (tid + k * NT) >> 2;
+    hcode[k] = hp < C::HPMAX ? s_hxy[hp] : -1;
+  }
+
+  struct Item { int co0, n0, y0, x0; };
+  auto decode = [&](int item) {
+    Item it;
+    it.co0 = (item % p.nCoT) * BN; item /= p.nCoT;
+    it.x0 = (item % p.tilesX) * p.TW; item /= p.tilesX;
+    it.y0 = (item % p.tilesY) * p.TH;
+    it.n0 = (item / p.tilesY) * p.NI;
+    return it;
+  };
+
+  int hgp[C::UH];   // global pixel of each staging unit for the item being LOADED: >=0, -1 zero pad
+  auto set_hgp = [&](const Item& it) {
+#pragma unroll
+    for (int k = 0; k < C::UH; ++k) {
+      int gp = -1;
+      if (hcode[k] >= 0) {
+        const int n = it.n0 + (hcode[k] >> 20), y = it.y0 + ((hcode[k] >> 10) & 1023) - 1, x = it.x0 + (hcode[k] & 1023) - 1;
+        if (n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W) gp = (n * p.H + y) * p.W + x;
+      }
+      hgp[k] = gp;
+    }
+  };
 
   Vec16<T> hreg[C::UH];
   Vec16<T> wreg[C::UW];
-
-  auto load_regs = [&](int kb, int kc) {
+  // units past the valid channels of a chunk are zero-filled, so every chunk runs KS full k-steps
+  auto load_regs = [&](const Item& it, int kb, int kc) {
     const T* src; int ch, pitch;
     if (kb < p.C0) { src = (const T*)p.src0; ch = kb; pitch = p.P0; }
     else { src = (const T*)p.src1; ch = kb - p.C0; pitch = p.P1; }
@@ -154,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       const int row = u >> 2, seg = u & 3;
       if (row < 9 * BN && seg * EPV < kc) {
         const int tap = row / BN, co = row - tap * BN;
-        wreg[k] = ld16((const T*)p.w + ((size_t)(tap * p.Cout + co0 + co)) * p.Cin + kb + seg * EPV);
+        wreg[k] = ld16((const T*)p.w + ((size_t)(tap * p.Cout + it.co0 + co)) * p.Cin + kb + seg * EPV);
       } else wreg[k] = zero16<T>();
     }
   };
@@ -162,7 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
 #pragma unroll
     for (int k = 0; k < C::UH; ++k) {
       const int u = tid + k * NT;
-      if (hgp[k] != -2) st16(&s_halo[(u >> 2) * PS + (u & 3) * EPV], hreg[k]);
+      if ((u >> 2) < C::HPMAX) st16(&s_halo[(u >> 2) * PS + (u & 3) * EPV], hreg[k]);
     }
 #pragma unroll
     for (int k = 0; k < C::UW; ++k) {
@@ -179,91 +217,140 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
+  int item = blockIdx.x;
+  if (item >= p.nItems) return;
+  Item cur = decode(item);
+  set_hgp(cur);
   int kb = 0;
   int kc = min(C::KC, (kb < p.C0 ? p.C0 : p.Cin) - kb);
-  load_regs(kb, kc);
-  __syncthreads();  // tables visible
-  int abase[SM];
-#pragma unroll
-  for (int a = 0; a < SM; ++a) abase[a] = s_hidx[(wm * SM + a) * 32 + r] * PS;
+  load_regs(cur, kb, kc);
+  bool first_chunk = true;
+  constexpr int NSTEP = 9 * KS;
 
-  while (kb < p.Cin) {
-    __syncthreads();  // previous chunk's reads done
+  while (true) {
+    __syncthreads();  // previous chunk's fragment reads / previous item's epilogue reads are done
     write_lds();
-    __syncthreads();
-    const int kc_cur = kc;
-    kb += kc_cur;
-    if (kb < p.Cin) {
-      kc = min(C::KC, (kb < p.C0 ? p.C0 : p.Cin) - kb);
-      load_regs(kb, kc);
+    if (first_chunk) {
+      for (int m = tid; m < BM; m += NT) {
+        const int code = s_mxy[m];
+        int gp = -1;
+        if (code >= 0) {
+          const int n = cur.n0 + (code >> 20), y = cur.y0 + ((code >> 10) & 1023), x = cur.x0 + (code & 1023);
+          if (n < p.N && y < p.H && x < p.W) gp = (n * p.H + y) * p.W + x;
+        }
+        s_gpix[m] = gp;
+      }
     }
-    const int ksteps = kc_cur >> 4;
+    __syncthreads();
+    // prefetch the next (item, chunk) into registers
+    int nkb = kb + kc, nkc = 0, nitem = item;
+    Item nxt = cur;
+    bool have_next = true;
+    const bool last_chunk = nkb >= p.Cin;
+    if (last_chunk) {
+      nkb = 0;
+      nitem = item + gridDim.x;
+      if (nitem < p.nItems) { nxt = decode(nitem); set_hgp(nxt); }
+      else have_next = false;
+    }
+    if (have_next) {
+      nkc = min(C::KC, (nkb < p.C0 ? p.C0 : p.Cin) - nkb);
+      load_regs(nxt, nkb, nkc);
+    }
+    // fully unrolled tap x k-step sweep; fragments of step s+1 are read while step s multiplies
+    {
+      typename M::Frag fa[2][SM], fb[2][SN];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PS;
-      for (int ks = 0; ks < ksteps; ++ks) {
-        typename M::Frag fb[SN], fa[SM];
+      for (int a = 0; a < SM; ++a) fa[0][a] = M::load(&s_halo[abase[a] + toff[0]]);
 #pragma unroll
-        for (int b = 0; b < SN; ++b)
-          fb[b] = M::load(&s_w[(tap * BN + (wn * SN + b) * 32 + r) * PS + ks * 16 + 8 * h]);
+      for (int b = 0; b < SN; ++b) fb[0][b] = M::load(&s_w[bbase + b * 32 * PS]);
 #pragma unroll
-        for (int a = 0; a < SM; ++a) fa[a] = M::load(&s_halo[abase[a] + toff + ks * 16 + 8 * h]);
+      for (int st = 0; st < NSTEP; ++st) {
+        const int cu = st & 1;
+        if (st + 1 < NSTEP) {
+          const int tap = (st + 1) / KS, ks = (st + 1) % KS;
+#pragma unroll
+          for (int a = 0; a < SM; ++a) fa[cu ^ 1][a] = M::load(&s_halo[abase[a] + toff[tap] + ks * 16]);
+#pragma unroll
+          for (int b = 0; b < SN; ++b) fb[cu ^ 1][b] = M::load(&s_w[bbase + (tap * BN + b * 32) * PS + ks * 16]);
+        }
 #pragma unroll
         for (int a = 0; a < SM; ++a)
 #pragma unroll
-          for (int b = 0; b < SN; ++b) M::mma(acc[a][b], fa[a], fb[b]);
+          for (int b = 0; b < SN; ++b) M::mma(acc[a][b], fa[cu][a], fb[cu][b]);
       }
     }
-  }
-
-  // ---- epilogue: bias, optional accumulate, store, BN partial sums ----------
+    first_chunk = false;
+    if (last_chunk) {
+      // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
+      __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
+      T* const s_out = s_buf;
 #pragma unroll
-  for (int b = 0; b < SN; ++b) {
-    const int co = co0 + (wn * SN + b) * 32 + r;
-    const float bias = p.bias ? p.bias[co] : 0.f;
-    T* dst; int pitch, cc; bool accum;
-    if (co < p.D0) {
-      dst = (T*)p.dst0; pitch = p.Q0; cc = co;
-      accum = (p.acc0_mask >> (p.slot_w > 0 ? co / p.slot_w : 0)) & 1u;
-    } else {
-      dst = (T*)p.dst1; pitch = p.Q1; cc = co - p.D0; accum = p.acc1 != 0;
-    }
-    float s1 = 0.f, s2 = 0.f;
+      for (int b = 0; b < SN; ++b) {
+        const int cl = (wn * SN + b) * 32 + r;  // channel within the tile
+        const float bias = p.bias ? p.bias[cur.co0 + cl] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int a = 0; a < SM; ++a) {
+        for (int a = 0; a < SM; ++a) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = (wm * SM + a) * 32 + acc_row(i, h);
-        const int gp = s_gpix[m];
-        if (gp >= 0) {
-          T* q = dst + (size_t)gp * pitch + cc;
-          float v = acc[a][b][i] + bias;
-          if (accum) v += to_f32(*q);
-          const T tv = from_f32<T>(v);
-          *q = tv;
-          const float d = to_f32(tv) - bias;
-          s1 += d; s2 += d * d;
+          for (int i = 0; i < 16; ++i) {
+            const int m = (wm * SM + a) * 32 + acc_row(i, h);
+            const T tv = from_f32<T>(acc[a][b][i] + bias);
+            s_out[m * OS + cl] = tv;
+            if (p.stats && s_gpix[m] >= 0) {
+              const float d = to_f32(tv) - bias;
+              s1 += d; s2 += d * d;
+            }
+            acc[a][b][i] = 0.f;
+          }
+        }
+        if (p.stats) {
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (h == 0) { s_red[(wm * BN + cl) * 2 + 0] = s1; s_red[(wm * BN + cl) * 2 + 1] = s2; }
         }
       }
-    }
-    if (p.stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        s_red[(wm * BN + (wn * SN + b) * 32 + r) * 2 + 0] = s1;
-        s_red[(wm * BN + (wn * SN + b) * 32 + r) * 2 + 1] = s2;
-      }
-    }
-  }
-  if (p.stats) {
-    __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-      float s1 = 0.f, s2 = 0.f;
+      __syncthreads();
+      constexpr int SEGS = BN / EPV;
 #pragma unroll
-      for (int k = 0; k < WM; ++k) { s1 += s_red[(k * BN + c) * 2]; s2 += s_red[(k * BN + c) * 2 + 1]; }
-      atomicAdd(&p.stats[co0 + c], s1);
-      atomicAdd(&p.stats[p.Cout + co0 + c], s2);
+      for (int k = 0; k < C::UO; ++k) {
+        const int u = tid + k * NT;
+        const int m = u / SEGS, seg = u - m * SEGS;
+        if (m < BM) {
+          const int gp = s_gpix[m];
+          if (gp >= 0) {
+            const int co = cur.co0 + seg * EPV;
+            T* q; bool accum;
+            if (co < p.D0) {
+              q = (T*)p.dst0 + (size_t)gp * p.Q0 + co;
+              accum = (p.acc0_mask >> (p.slot_w > 0 ? co / p.slot_w : 0)) & 1u;
+            } else {
+              q = (T*)p.dst1 + (size_t)gp * p.Q1 + (co - p.D0);
+              accum = p.acc1 != 0;
+            }
+            Vec16<T> v = ld16(&s_out[m * OS + seg * EPV]);
+            if (accum) {
+              const Vec16<T> o = ld16(q);
+#pragma unroll
+              for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + o.get(e));
+            }
+            st16(q, v);
+          }
+        }
+      }
+      if (p.stats) {
+        for (int c = tid; c < BN; c += NT) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < WM; ++k) { s1 += s_red[(k * BN + c) * 2]; s2 += s_red[(k * BN + c) * 2 + 1]; }
+          atomicAdd(&p.stats[cur.co0 + c], s1);
+          atomicAdd(&p.stats[p.Cout + cur.co0 + c], s2);
+        }
+      }
+      if (!have_next) break;
+      cur = nxt; item = nitem; first_chunk = true;
     }
+    kb = nkb; kc = nkc;
   }
 }
 
@@ -304,7 +391,16 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG;
   p.nCoT = p.Cout / C::BN;
-  const long grid = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
+  const long items = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
+  p.nItems = (int)items;
+  // persistent grid: resident workgroups only, item counts balanced across them
+  const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN;
+  long per_cu = (long)(160 * 1024 / lds_bytes);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 2048 / C::NT) per_cu = 2048 / C::NT;
+  const long resident = 256 * per_cu;
+  const long rounds = (items + resident - 1) / resident;
+  const long grid = (items + rounds - 1) / rounds;
   const double px = (double)d->N * d->H * d->W;
   const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
   ProfScope ps(C::BN == 32 ? PC_CONV_M256N32 : PC_CONV_M128N64, 2.0 * 9 * acin * p.Cout * px,
@@ -337,6 +433,13 @@ extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {
 
 // ---------------------------------------------------------------------------
 // wgrad kernel
+//
+// Work item = (32 Cout) x (32 Cin) x 9 taps of dW, over a slice of the pixel tiles.
+// All 4 waves of a workgroup accumulate the SAME output block over different pixels of
+// each 128-pixel tile (intra-workgroup split of the contraction), so no wave idles for
+// narrow layers; partials are summed through LDS once, then added atomically to the fp32
+// gradient. Tiles are double-buffered in LDS; the next tile's global loads are in flight
+// (in registers) while the current one multiplies.
 // ---------------------------------------------------------------------------
 struct WgP {
   const void* src0; const void* src1;
@@ -348,19 +451,16 @@ struct WgP {
   int nCoT, nCiT, ksplit, nMT;
 };
 
-// smallest row stride (elements) >= c with (2*stride) % 128 == 64: conflict-free
-// for ds_read_b64_tr_b16 (4 rows x 64 B per 32-lane half land on distinct banks)
-constexpr int tr_stride(int c) { return ((c - 32 + 63) / 64) * 64 + 32; }
-
-template <typename T, int WCO_, int WCI_> struct WgCfg {
-  static constexpr int WCO = WCO_, WCI = WCI_;
-  static constexpr int NT = 64 * WCO * WCI;
-  static constexpr int BCO = 32 * WCO, BCI = 32 * WCI;
+template <typename T> struct WgCfg {
+  static constexpr int NT = 256;
   static constexpr int BM = 128, HPMAX = 192;
   static constexpr int EPV = Tr<T>::EPV;
   static constexpr bool F32 = std::is_same<T, float>::value;
-  static constexpr int SY = F32 ? BCO : tr_stride(BCO);
-  static constexpr int SA = F32 ? BCI : tr_stride(BCI);
+  static constexpr int SR = 32;                       // row stride (elements): 32 channels, no pad
+  static constexpr int UPP = 32 / EPV;                // 16-byte units per pixel row
+  static constexpr int NUD = BM * UPP / NT;           // dY units per thread
+  static constexpr int NUA = HPMAX * UPP / NT;        // halo units per thread
+  static constexpr int STAGE = (BM + HPMAX) * SR;     // elements per LDS stage
 };
 
 template <typename T>
@@ -372,28 +472,98 @@ __device__ __forceinline__ s16x4 tr_read(const T* p) {
 template <typename T> struct Frag16;
 template <> struct Frag16<bf16_t> { typedef bf16x8 V; };
 template <> struct Frag16<f16_t> { typedef f16x8 V; };
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-template <typename T, int WCO, int WCI>
-__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_kernel(WgP p) {
-  typedef WgCfg<T, WCO, WCI> C;
-  constexpr int NT = C::NT, BM = C::BM, EPV = C::EPV, SY = C::SY, SA = C::SA;
-  __shared__ __attribute__((aligned(16))) T s_dy[BM * SY];
-  __shared__ __attribute__((aligned(16))) T s_a[C::HPMAX * SA];
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {
+  typedef WgCfg<T> C;
+  constexpr int NT = C::NT, BM = C::BM, EPV = C::EPV, SR = C::SR, UPP = C::UPP;
+  __shared__ __attribute__((aligned(16))) T s_stage[2 * C::STAGE];
   __shared__ int s_hidx[BM];
-  __shared__ int s_gpix[BM];
+  __shared__ int s_mxy[BM];
+  __shared__ int s_hxy[C::HPMAX];
+  __shared__ float s_red[3 * 16 * 64];   // cross-wave reduction, one tap at a time
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wco = wave / WCI, wci = wave % WCI;
   const int r = lane & 31, h = lane >> 5;
 
   int bid = blockIdx.x;
   const int cit = bid % p.nCiT; bid /= p.nCiT;
   const int cot = bid % p.nCoT;
   const int split = bid / p.nCoT;
-  const int co0 = cot * C::BCO, ci0 = cit * C::BCI;
+  const int co0 = cot * 32, ci0 = cit * 32;
   const int HW2 = p.TW + 2, HH2 = p.TH + 2;
   const int HP = p.NI * HH2 * HW2;
   const int THW = p.TH * p.TW;
+
+  for (int m = tid; m < BM; m += NT) {
+    const int ni = m / THW;
+    const int rem = m - ni * THW;
+    const int ly = rem / p.TW, lx = rem - ly * p.TW;
+    const bool ok = ni < p.NI;
+    s_hidx[m] = ok ? ((ni * HH2 + ly + 1) * HW2 + lx + 1) : (HW2 + 1);
+    s_mxy[m] = ok ? ((ni << 20) | (ly << 10) | lx) : -1;
+  }
+  for (int hp = tid; hp < C::HPMAX; hp += NT) {
+    int code = -1;
+    if (hp < HP) {
+      const int ni = hp / (HH2 * HW2);
+      const int rem = hp - ni * (HH2 * HW2);
+      const int hy = rem / HW2, hx = rem - hy * HW2;
+      code = (ni << 20) | (hy << 10) | hx;
+    }
+    s_hxy[hp] = code;
+  }
+  __syncthreads();
+
+  // tile-invariant staging codes of this thread's units
+  int dcode[C::NUD], acode[C::NUA];
+#pragma unroll
+  for (int k = 0; k < C::NUD; ++k) dcode[k] = s_mxy[(tid + k * NT) / UPP];
+#pragma unroll
+  for (int k = 0; k < C::NUA; ++k) acode[k] = s_hxy[(tid + k * NT) / UPP];
+  // the channel slice of the forward input this item reads: one source per 16-byte unit
+  // (C0 is a multiple of 16, so a unit never straddles the two concat sources)
+  const int seg = tid % UPP;                 // same for all units of a thread (NT % UPP == 0)
+  const int cch = ci0 + seg * EPV;
+  const bool cvalid = cch < p.Cin;
+  const T* asrc; int apitch, ach;
+  if (cch < p.C0) { asrc = (const T*)p.src0; apitch = p.P0; ach = cch; }
+  else { asrc = (const T*)p.src1; apitch = p.P1; ach = cch - p.C0; }
+  const T* dsrc = (const T*)p.dy + co0 + seg * EPV;
+
+  Vec16<T> dreg[C::NUD], areg[C::NUA];
+  auto load_tile = [&](int mt) {
+    int b2 = mt;
+    const int x0 = (b2 % p.tilesX) * p.TW; b2 /= p.tilesX;
+    const int y0 = (b2 % p.tilesY) * p.TH;
+    const int n0 = (b2 / p.tilesY) * p.NI;
+#pragma unroll
+    for (int k = 0; k < C::NUD; ++k) {
+      dreg[k] = zero16<T>();
+      if (dcode[k] >= 0) {
+        const int n = n0 + (dcode[k] >> 20), y = y0 + ((dcode[k] >> 10) & 1023), x = x0 + (dcode[k] & 1023);
+        if (n < p.N && y < p.H && x < p.W) dreg[k] = ld16(dsrc + ((size_t)(n * p.H + y) * p.W + x) * p.PY);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < C::NUA; ++k) {
+      areg[k] = zero16<T>();
+      if (acode[k] >= 0 && cvalid) {
+        const int n = n0 + (acode[k] >> 20), y = y0 + ((acode[k] >> 10) & 1023) - 1, x = x0 + (acode[k] & 1023) - 1;
+        if (n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W)
+          areg[k] = ld16(asrc + ((size_t)(n * p.H + y) * p.W + x) * apitch + ach);
+      }
+    }
+  };
+  auto write_tile = [&](int buf) {
+    T* sd = s_stage + buf * C::STAGE;
+    T* sa = sd + BM * SR;
+#pragma unroll
+    for (int k = 0; k < C::NUD; ++k) st16(&sd[((tid + k * NT) / UPP) * SR + seg * EPV], dreg[k]);
+#pragma unroll
+    for (int k = 0; k < C::NUA; ++k) st16(&sa[((tid + k * NT) / UPP) * SR + seg * EPV], areg[k]);
+  };
 
   f32x16 acc[9];
 #pragma unroll
@@ -401,131 +571,105 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_kernel(WgP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  for (int mt = split; mt < p.nMT; mt += p.ksplit) {
-    int b2 = mt;
-    const int tx = b2 % p.tilesX; b2 /= p.tilesX;
-    const int ty = b2 % p.tilesY;
-    const int tg = b2 / p.tilesY;
-    const int x0 = tx * p.TW, y0 = ty * p.TH, n0 = tg * p.NI;
-
-    __syncthreads();  // previous tile fully consumed
-    for (int m = tid; m < BM; m += NT) {
-      const int ni = m / THW;
-      const int rem = m - ni * THW;
-      const int ly = rem / p.TW, lx = rem - ly * p.TW;
-      const int n = n0 + ni, y = y0 + ly, x = x0 + lx;
-      const bool ok = ni < p.NI && n < p.N && y < p.H && x < p.W;
-      s_hidx[m] = ok ? ((ni * HH2 + ly + 1) * HW2 + lx + 1) : (HW2 + 1);
-      s_gpix[m] = ok ? ((n * p.H + y) * p.W + x) : -1;
-    }
-    __syncthreads();
-    // stage dY tile [BM][BCO]
-    constexpr int UY = C::BCO / EPV;
-    for (int u = tid; u < BM * UY; u += NT) {
-      const int m = u / UY, seg = u - m * UY;
-      const int gp = s_gpix[m];
-      const int co = co0 + seg * EPV;
-      Vec16<T> v = zero16<T>();
-      if (gp >= 0 && co < p.Cout) v = ld16((const T*)p.dy + (size_t)gp * p.PY + co);
-      st16(&s_dy[m * SY + seg * EPV], v);
-    }
-    // stage X halo [HP][BCI]
-    constexpr int UA = C::BCI / EPV;
-    for (int u = tid; u < HP * UA; u += NT) {
-      const int hp = u / UA, seg = u - hp * UA;
-      const int ni = hp / (HH2 * HW2);
-      const int rem = hp - ni * (HH2 * HW2);
-      const int hy = rem / HW2, hx = rem - hy * HW2;
-      const int n = n0 + ni, y = y0 + hy - 1, x = x0 + hx - 1;
-      const int c = ci0 + seg * EPV;
-      Vec16<T> v = zero16<T>();
-      if (n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && c < p.Cin) {
-        const size_t gp = ((size_t)n * p.H + y) * p.W + x;
-        v = (c < p.C0) ? ld16((const T*)p.src0 + gp * p.P0 + c)
-                       : ld16((const T*)p.src1 + gp * p.P1 + (c - p.C0));
-      }
-      st16(&s_a[hp * SA + seg * EPV], v);
-    }
-    __syncthreads();
-
-    if constexpr (C::F32) {
-      for (int k0 = 0; k0 < BM; k0 += 2) {
-        const int m = k0 + h;
-        const float av = s_dy[m * SY + wco * 32 + r];
-        const int hx = s_hidx[m];
+  // per-lane LDS offsets of this wave's pixels (tile-invariant)
+  int toff[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int toff = (tap / 3 - 1) * HW2 + (tap % 3 - 1);
-          const float bv = s_a[(hx + toff) * SA + wci * 32 + r];
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
-        }
+  for (int tap = 0; tap < 9; ++tap) toff[tap] = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * SR;
+
+  int mt = split;
+  if (mt < p.nMT) load_tile(mt);
+  int buf = 0;
+  if (mt < p.nMT) write_tile(0);
+  __syncthreads();
+  while (mt < p.nMT) {
+    const int nmt = mt + p.ksplit;
+    if (nmt < p.nMT) load_tile(nmt);   // in flight during the MFMAs below
+    const T* sd = s_stage + buf * C::STAGE;
+    const T* sa = sd + BM * SR;
+    if constexpr (C::F32) {
+      // wave w owns pixels [32w, 32w+32): 16 k-steps of 2 pixels (lane half h picks the pixel)
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        const int m = wave * 32 + kk * 2 + h;
+        const float av = sd[m * SR + r];
+        const int hx = s_hidx[m] * SR + r;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sa[hx + toff[tap]], acc[tap], 0, 0, 0);
       }
     } else {
       typedef typename Frag16<T>::V FV;
-      const int q = (lane >> 2) & 3;                       // row within the 4-row block
+      const int q = (lane >> 2) & 3;                             // row within the 4-row block
       const int colo = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);  // column offset supplied by this lane
-      for (int k0 = 0; k0 < BM; k0 += 16) {
-        const int m0 = k0 + 8 * h + q, m1 = m0 + 4;
-        const int hx0 = s_hidx[m0], hx1 = s_hidx[m1];
-        const s16x4 a0 = tr_read(&s_dy[m0 * SY + wco * 32 + colo]);
-        const s16x4 a1 = tr_read(&s_dy[m1 * SY + wco * 32 + colo]);
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int m0 = wave * 32 + kk * 16 + 8 * h + q, m1 = m0 + 4;
+        const int b0 = s_hidx[m0] * SR + colo, b1 = s_hidx[m1] * SR + colo;
+        const s16x4 a0 = tr_read(&sd[m0 * SR + colo]);
+        const s16x4 a1 = tr_read(&sd[m1 * SR + colo]);
         const s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        s16x4 x0[9], x1[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) { x0[tap] = tr_read(&sa[b0 + toff[tap]]); x1[tap] = tr_read(&sa[b1 + toff[tap]]); }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int toff = (tap / 3 - 1) * HW2 + (tap % 3 - 1);
-          const s16x4 b0 = tr_read(&s_a[(hx0 + toff) * SA + wci * 32 + colo]);
-          const s16x4 b1 = tr_read(&s_a[(hx1 + toff) * SA + wci * 32 + colo]);
-          const s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const s16x8 bv = __builtin_shufflevector(x0[tap], x1[tap], 0, 1, 2, 3, 4, 5, 6, 7);
           Mma<T>::mma(acc[tap], __builtin_bit_cast(FV, av), __builtin_bit_cast(FV, bv));
         }
       }
     }
+    if (nmt < p.nMT) write_tile(buf ^ 1);   // the other stage was last read one iteration ago
+    __syncthreads();
+    buf ^= 1;
+    mt = nmt;
   }
 
-  // atomically accumulate the partial dW tile
-  const int ci = ci0 + wci * 32 + r;
-  if (ci < p.Cin) {
+  // cross-wave reduction (one tap at a time through LDS), then one atomic per output element
+  const int ci = ci0 + r;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+  for (int tap = 0; tap < 9; ++tap) {
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_red[((wave - 1) * 16 + i) * 64 + lane] = acc[tap][i];
+    }
+    __syncthreads();
+    if (wave == 0 && ci < p.Cin) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int co = co0 + wco * 32 + acc_row(i, h);
-        if (co < p.Cout) atomicAdd(&p.dw[((size_t)tap * p.Cout + co) * p.Cin + ci], acc[tap][i]);
+        const float v = acc[tap][i] + s_red[(0 * 16 + i) * 64 + lane] + s_red[(1 * 16 + i) * 64 + lane] + s_red[(2 * 16 + i) * 64 + lane];
+        const int co = co0 + acc_row(i, h);
+        if (co < p.Cout) atomicAdd(&p.dw[((size_t)tap * p.Cout + co) * p.Cin + ci], v);
       }
     }
+    __syncthreads();
   }
 }
 
-template <typename T, int WCO, int WCI>
-static int launch_wgrad_cfg(const nunet_wgrad_desc* d, hipStream_t st) {
-  typedef WgCfg<T, WCO, WCI> C;
+template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStream_t st) {
+  typedef WgCfg<T> C;
   WgP p;
   p.src0 = d->src0; p.src1 = d->src1; p.C0 = d->C0; p.C1 = d->C1; p.P0 = d->P0; p.P1 = d->P1;
   p.dy = d->dy; p.Cout = d->Cout; p.PY = d->PY; p.dw = d->dw;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1;
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG;
-  p.nCoT = ceil_div(p.Cout, C::BCO);
-  p.nCiT = ceil_div(p.Cin, C::BCI);
+  p.nCoT = ceil_div(p.Cout, 32);
+  p.nCiT = ceil_div(p.Cin, 32);
   p.nMT = g.tilesX * g.tilesY * g.tilesG;
   const int otiles = p.nCoT * p.nCiT;
-  int ks = ceil_div(512, otiles);
+  static int wg_target = 0;
+  if (!wg_target) { const char* e = getenv("NUNET_WG_TARGET"); wg_target = e ? atoi(e) : 320; }
+  int ks = ceil_div(wg_target, otiles);
   if (ks > p.nMT) ks = p.nMT;
   if (ks < 1) ks = 1;
   p.ksplit = ks;
   const long grid = (long)otiles * ks;
   const double px = (double)d->N * d->H * d->W;
   const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
-  ProfScope ps(WCO == 1 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, 2.0 * 9 * acin * p.Cout * px,
+  ProfScope ps(p.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, 2.0 * 9 * acin * p.Cout * px,
                px * (acin + p.Cout) * sizeof(T) + 9.0 * acin * p.Cout * 4, st);
-  hipLaunchKernelGGL((wgrad_kernel<T, WCO, WCI>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  hipLaunchKernelGGL((wgrad_kernel<T>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   return nunet_check_launch("wgrad3x3");
-}
-
-template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStream_t st) {
-  if (d->Cout % 64 == 0) return launch_wgrad_cfg<T, 2, 2>(d, st);
-  return launch_wgrad_cfg<T, 1, 4>(d, st);
 }
 
 extern "C" int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s) {

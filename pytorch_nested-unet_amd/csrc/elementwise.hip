@@ -106,22 +106,19 @@ __device__ __forceinline__ void bn_channel_coeffs(const BnFwdP& p, int c, float 
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   constexpr int EPV = Tr<T>::EPV;
+  __shared__ float s_sc[2048], s_sh[2048];
   const int G = p.C / EPV;  // channel groups; 256 % G == 0
   const int cg = threadIdx.x % G;
   const float M = (float)p.N * p.H * p.W;
-  float sc[EPV], sh[EPV];
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) {
-    const int c = cg * EPV + e;
+  // per-channel coefficients once per block (not per thread), block 0 also owns the
+  // running-stat update and the saved mean/invstd for backward
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
     float mean, invstd, var, mf;
     bn_channel_coeffs(p, c, M, mean, invstd, var, mf);
-    sc[e] = p.gamma[c] * invstd;
-    sh[e] = p.beta[c] - mean * sc[e];
-  }
-  if (blockIdx.x == 0 && p.training) {
-    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-      float mean, invstd, var, mf;
-      bn_channel_coeffs(p, c, M, mean, invstd, var, mf);
+    const float sc = p.gamma[c] * invstd;
+    s_sc[c] = sc;
+    s_sh[c] = p.beta[c] - mean * sc;
+    if (blockIdx.x == 0 && p.training) {
       p.save[c] = mean;
       p.save[p.C + c] = invstd;
       if (p.rm) {
@@ -130,8 +127,12 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
         p.rv[c] = (1.f - p.momentum) * p.rv[c] + p.momentum * unb;
       }
     }
-    if (threadIdx.x == 0 && p.nbt) *p.nbt += 1;
   }
+  if (blockIdx.x == 0 && p.training && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
+  __syncthreads();
+  float sc[EPV], sh[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) { sc[e] = s_sc[cg * EPV + e]; sh[e] = s_sh[cg * EPV + e]; }
   const int ppb = blockDim.x / G;  // pixels (or quads) per block iteration
   const int pl = threadIdx.x / G;
   if constexpr (!POOL) {
@@ -187,10 +188,10 @@ template <typename T> static int launch_bn_fwd(const nunet_bn_fwd_desc* d, hipSt
   ProfScope ps(PC_BN_FWD, 0, (double)d->N * d->H * d->W * d->C * sizeof(T) * (d->pooled ? 2.25 : 2.0), st);
   if (d->pooled) {
     const int64_t nq = (int64_t)d->N * (d->H / 2) * (d->W / 2);
-    hipLaunchKernelGGL((bn_relu_fwd_kernel<T, true>), dim3(grid_for(nq, ppb)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((bn_relu_fwd_kernel<T, true>), dim3(grid_for(nq, ppb * 2, 2048)), dim3(256), 0, st, p);
   } else {
     const int64_t np = (int64_t)d->N * d->H * d->W;
-    hipLaunchKernelGGL((bn_relu_fwd_kernel<T, false>), dim3(grid_for(np, ppb)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((bn_relu_fwd_kernel<T, false>), dim3(grid_for(np, ppb * 4, 2048)), dim3(256), 0, st, p);
   }
   return nunet_check_launch("bn_relu_fwd");
 }
@@ -220,27 +221,28 @@ struct BnBwdP {
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
   constexpr int EPV = Tr<T>::EPV;
-  __shared__ float s_acc[2 * 512 * 4];  // [2][C] (C <= 2048 for EPV 8; asserted on host: C <= 2048)
+  constexpr int NV = APPLY ? 1 : 2;                 // partial sums per channel
+  __shared__ float s_co[6 * 2048 / 4];              // coefficient tables, C <= 512: [6][C]
+  __shared__ float s_part[256 * NV * EPV];          // per-thread partials for the block reduction
   const int G = p.C / EPV;
   const int cg = threadIdx.x % G;
   const int ppb = blockDim.x / G, pl = threadIdx.x / G;
   const float M = (float)p.N * p.H * p.W;
-  float sc[EPV], sh[EPV], mean[EPV], istd[EPV], k1[EPV], k2[EPV], gi[EPV];
+  const int C = p.C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float mean = p.mi[c], istd = p.mi[C + c];
+    const float sc = p.gamma[c] * istd;
+    s_co[c] = mean; s_co[C + c] = istd; s_co[2 * C + c] = sc; s_co[3 * C + c] = p.beta[c] - mean * sc;
+    if constexpr (APPLY) { s_co[4 * C + c] = p.sums[c] / M; s_co[5 * C + c] = p.sums[C + c] / M; }
+  }
+  __syncthreads();
+  float sc[EPV], sh[EPV], mean[EPV], istd[EPV], k1[EPV], k2[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; ++e) {
     const int c = cg * EPV + e;
-    mean[e] = p.mi[c];
-    istd[e] = p.mi[p.C + c];
-    sc[e] = p.gamma[c] * istd[e];
-    sh[e] = p.beta[c] - mean[e] * sc[e];
-    if constexpr (APPLY) {
-      k1[e] = p.sums[c] / M;
-      k2[e] = p.sums[p.C + c] / M;
-      gi[e] = sc[e];
-    }
+    mean[e] = s_co[c]; istd[e] = s_co[C + c]; sc[e] = s_co[2 * C + c]; sh[e] = s_co[3 * C + c];
+    if constexpr (APPLY) { k1[e] = s_co[4 * C + c]; k2[e] = s_co[5 * C + c]; }
   }
-  for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) s_acc[c] = 0.f;
-  __syncthreads();
   float a1[EPV], a2[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
       const float dz = act > 0.f ? vd.get(e) : 0.f;
       const float xh = (yv - mean[e]) * istd[e];
       if constexpr (APPLY) {
-        const float dyv = gi[e] * (dz - k1[e] - xh * k2[e]);
+        const float dyv = sc[e] * (dz - k1[e] - xh * k2[e]);
         o.set(e, dyv);
         a1[e] += o.get(e);
       } else {
@@ -266,23 +268,28 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
     }
     if constexpr (APPLY) st16((T*)p.dy + pix * p.PDY + cg * EPV, o);
   }
+  // block reduction over the ppb threads that share a channel group, then one atomic per channel
 #pragma unroll
   for (int e = 0; e < EPV; ++e) {
-    atomicAdd(&s_acc[cg * EPV + e], a1[e]);
-    if constexpr (!APPLY) atomicAdd(&s_acc[p.C + cg * EPV + e], a2[e]);
+    s_part[(threadIdx.x * NV + 0) * EPV + e] = a1[e];
+    if constexpr (!APPLY) s_part[(threadIdx.x * NV + 1) * EPV + e] = a2[e];
   }
   __syncthreads();
+  for (int t = threadIdx.x; t < NV * C; t += blockDim.x) {
+    const int v = t / C, c = t - v * C;
+    const int g = c / EPV, e = c - g * EPV;
+    float sum = 0.f;
+    for (int q = 0; q < ppb; ++q) sum += s_part[((q * G + g) * NV + v) * EPV + e];
+    if constexpr (APPLY) { if (p.dbias) atomicAdd(&p.dbias[c], sum); }
+    else atomicAdd(&p.sums[v * C + c], sum);
+  }
   if constexpr (APPLY) {
-    if (p.dbias)
-      for (int c = threadIdx.x; c < p.C; c += blockDim.x) atomicAdd(&p.dbias[c], s_acc[c]);
     if (blockIdx.x == 0) {
-      for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+      for (int c = threadIdx.x; c < C; c += blockDim.x) {
         if (p.dbeta) p.dbeta[c] += p.sums[c];
-        if (p.dgamma) p.dgamma[c] += p.sums[p.C + c];
+        if (p.dgamma) p.dgamma[c] += p.sums[C + c];
       }
     }
-  } else {
-    for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) atomicAdd(&p.sums[c], s_acc[c]);
   }
 }
 
@@ -295,7 +302,8 @@ template <typename T, bool APPLY> static int launch_bn_bwd_t(const nunet_bn_bwd_
   const int64_t np = (int64_t)d->N * d->H * d->W;
   // fewer, fatter blocks: each block ends with 2C global atomics
   ProfScope ps(APPLY ? PC_BN_BWD_APPLY : PC_BN_BWD_REDUCE, 0, (double)np * d->C * sizeof(T) * (APPLY ? 3.0 : 2.0), st);
-  hipLaunchKernelGGL((bn_relu_bwd_kernel<T, APPLY>), dim3(grid_for(np, (256 / G) * 8, 1024)), dim3(256), 0, st, p);
+  // fat blocks: every block ends with C (2C) same-address global atomics
+  hipLaunchKernelGGL((bn_relu_bwd_kernel<T, APPLY>), dim3(grid_for(np, (256 / G) * 8, APPLY ? 1024 : 512)), dim3(256), 0, st, p);
   return nunet_check_launch(APPLY ? "bn_relu_bwd_apply" : "bn_relu_bwd_reduce");
 }
 template <typename T> static int launch_bn_bwd_reduce(const nunet_bn_bwd_desc* d, hipStream_t st) { return launch_bn_bwd_t<T, false>(d, st); }
@@ -304,7 +312,7 @@ template <typename T> static int launch_bn_bwd_apply(const nunet_bn_bwd_desc* d,
 static int bn_bwd_check(const nunet_bn_bwd_desc* d, bool apply) {
   NUNET_REQUIRE(d && d->da && d->y && d->mean_invstd && d->gamma && d->beta && d->sums, "bn_relu_bwd: null pointer");
   const int epv = 16 / dtype_size(d->dtype);
-  NUNET_REQUIRE(pow2(d->C) && d->C >= epv && d->C / epv <= 256 && d->C <= 2048, "bn_relu_bwd: C=%d unsupported", d->C);
+  NUNET_REQUIRE(pow2(d->C) && d->C >= epv && d->C / epv <= 256 && d->C <= 512, "bn_relu_bwd: C=%d unsupported (power of two <= 512)", d->C);
   NUNET_REQUIRE(d->PY % epv == 0 && d->PDA % epv == 0, "bn_relu_bwd: pitch alignment");
   if (apply) NUNET_REQUIRE(d->dy && d->PDY % epv == 0, "bn_relu_bwd_apply: dy");
   return NUNET_OK;
@@ -561,7 +569,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int PX, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx, int PDX, int accumulate, float* __restrict__ dw, float* __restrict__ db, int N, int H, int W, int C, int K) {
-  // C must be 32: lane&31 = channel
+  // C must be 32: lane&31 = channel; the 8 half-waves of a block walk disjoint pixels
+  __shared__ float s_w[8][HEAD_MAXK][33];
   const int c = threadIdx.x & 31;
   const int hwv = threadIdx.x >> 5;  // half-wave in block
   const int nhw = blockDim.x >> 5;
@@ -588,9 +597,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
       *q = from_f32<T>(accumulate ? to_f32(*q) + g : g);
     }
   }
-  for (int k = 0; k < K; ++k) {
-    atomicAdd(&dw[k * C + c], aw[k]);
-    if (c == 0) atomicAdd(&db[k], ab[k]);
+#pragma unroll
+  for (int k = 0; k < HEAD_MAXK; ++k) { s_w[hwv][k][c] = aw[k]; if (c == 0) s_w[hwv][k][32] = ab[k]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < K * 33; t += blockDim.x) {
+    const int k = t / 33, cc = t - k * 33;
+    float sum = 0.f;
+    for (int q = 0; q < nhw; ++q) sum += s_w[q][k][cc];
+    if (cc < 32) atomicAdd(&dw[k * C + cc], sum);
+    else atomicAdd(&db[k], sum);
   }
 }
 template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* b, float* logits, hipStream_t st) {
@@ -600,7 +615,7 @@ template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int
 }
 template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw, float* db, hipStream_t st) {
   ProfScope ps(PC_HEAD, 4.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) * (acc ? 3 : 2) + K * 4), st);
-  hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 8 * 16, 1024)), dim3(256), 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw, db, N, H, W, C, K);
+  hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 8 * 16, 512)), dim3(256), 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw, db, N, H, W, C, K);
   return nunet_check_launch("head_bwd");
 }
 extern "C" int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* b, float* logits, nunet_stream_t s) {

@@ -29,7 +29,7 @@ void nunet_prof_push(int cls, double flops, double bytes, hipStream_t st) {
 void nunet_prof_pop(hipStream_t st) { (void)hipEventRecord(g_recs.back().e1, st); }
 
 static const char* kNames[PC_COUNT] = {
-    "conv3x3_fwd_dgrad<BM256,BN32>", "conv3x3_fwd_dgrad<BM128,BN64>", "conv3x3_wgrad<1x4>", "conv3x3_wgrad<2x2>",
+    "conv3x3_fwd_dgrad<BM256,BN32>", "conv3x3_fwd_dgrad<BM128,BN64>", "conv3x3_wgrad(Cout=32)", "conv3x3_wgrad(Cout>=64)",
     "bn_relu_fwd(+pool)", "bn_relu_bwd_reduce", "bn_relu_bwd_apply", "upsample2x_fwd", "upsample2x_bwd",
     "maxpool2x2", "head_1x1", "pack_weights", "unpack_grads", "bce_dice+iou", "sgd_step", "layout"};
 
