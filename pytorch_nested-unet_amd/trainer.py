@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from .parallel import allreduce_flat_
 
 
 class TrainStep:
@@ -88,7 +89,7 @@ class TrainStep:
 
     def _allreduce(self):
         if self.world > 1:
-            dist.all_reduce(self.eng.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+            allreduce_flat_(self.eng.flat_grads, self.pg)
 
     def capture(self, inp, target):
         """Capture forward+loss+backward(+SGD) into hipGraphs. Needs one REAL batch for the
