@@ -214,6 +214,14 @@ int nunet_plan_forward(nunet_plan* p, const float* params, float* bnbuf, int64_t
 /* grads: flat fp32 in params order. accumulate: += instead of assign. */
 int nunet_plan_backward(nunet_plan* p, const float* params, const float* dlogits, void* arena,
                         float* grads, int32_t accumulate, nunet_stream_t s);
+/* Multi-lane issue (default on; env NUNET_MULTISTREAM=0 disables): the plan forks onto
+ * its own streams (one per pyramid level + one per level for weight gradients), with event
+ * dependencies per buffer, and re-joins `s` before returning control - all work is ordered
+ * before anything the caller enqueues on `s` afterwards, and a capture of `s` records the
+ * lanes as parallel branches of the same hipGraph. */
+int nunet_plan_set_multistream(nunet_plan* p, int32_t enable);
+/* use caller-owned streams as lanes (n >= 1, cycled over the 10 lanes) instead of the plan's own */
+int nunet_plan_set_lanes(nunet_plan* p, nunet_stream_t* lanes, int32_t n);
 /* debug/test access to an intermediate: name like "x0_0", "x2_1" (block
  * outputs, NHWC). Returns byte offset into arena; fills pitch/channels. */
 int64_t nunet_plan_feature(const nunet_plan* p, int32_t i, int32_t j, int32_t* pitch,

@@ -102,6 +102,8 @@ _SIG = {
     "nunet_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "nunet_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "nunet_plan_feature": (_i64, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "nunet_plan_set_multistream": (_i32, [_vp, _i32]),
+    "nunet_plan_set_lanes": (_i32, [_vp, C.POINTER(_vp), _i32]),
     "nunet_profile_begin": (_i32, []),
     "nunet_profile_end": (_i32, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
 }

@@ -6,7 +6,10 @@
 //   * packed KRSC weights (forward + flipped/transposed dgrad copies);
 //   * native-layout fp32 gradient scratch that a single kernel unpacks into the
 //     caller's flat OIHW gradient arena (reference parameters() order).
+#include <stdlib.h>
 #include <string.h>
+
+#include <initializer_list>
 
 #include <vector>
 
@@ -129,6 +132,19 @@ struct Node {
 };
 struct Head { long long w_off, b_off, gs; int slot; };
 
+#define NLANES 10
+struct PlanRt {  // runtime objects owned by the plan (host side only)
+  hipStream_t lanes[NLANES];
+  bool lanes_ok;
+  std::vector<hipEvent_t> events[2];   // [0] forward, [1] backward: an event is never re-recorded within one capture
+  size_t events_used[2];
+  int multistream;
+  bool lanes_external;
+  std::vector<hipStream_t> cap_streams;   // never-reused streams for capture-time lane continuation
+  size_t cap_next;
+};
+struct nunet_plan;
+static PlanRt* rt_of(nunet_plan* P);
 struct nunet_plan {
   nunet_plan_cfg cfg;
   int es;                       // element size of T
@@ -145,7 +161,8 @@ struct nunet_plan {
   size_t off_wpack; long long wpack_elems;
   size_t off_img;
   size_t X[5], GX[5];
-  size_t off_dy, off_da1, off_gup, off_gpin;
+  size_t off_dy[5][2], off_da1[5], off_gup[5], off_gpin[5];   // per-level backward scratch (dY ping-pong)
+  struct PlanRt* rt;
   size_t total;
   PackTab ptab; long long pack_maxn;
   UnpackTab utab; long long unpack_maxn;
@@ -247,20 +264,21 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     P->X[i] = bump(cur, (size_t)P->px[i] * P->PX[i] * P->es);
     P->GX[i] = bump(cur, (size_t)P->px[i] * P->PX[i] * P->es);
   }
-  size_t max_dy = 0, max_gup = 0, max_gpin = 0;
   for (size_t k = 0; k < P->exec.size(); ++k) {
     Node& n = P->exec[k];
     const int f = NBF[n.i];
     const size_t plane = (size_t)P->px[n.i] * f * P->es;
     n.y1 = bump(cur, plane); n.a1 = bump(cur, plane); n.y2 = bump(cur, plane);
-    if (n.up_slot >= 0) { n.up = bump(cur, (size_t)P->px[n.i] * NBF[n.i + 1] * P->es); if ((size_t)P->px[n.i] * NBF[n.i + 1] * P->es > max_gup) max_gup = (size_t)P->px[n.i] * NBF[n.i + 1] * P->es; }
-    if (n.in_prefix == 0 && n.i > 0) { n.pin = bump(cur, (size_t)P->px[n.i] * NBF[n.i - 1] * P->es); if ((size_t)P->px[n.i] * NBF[n.i - 1] * P->es > max_gpin) max_gpin = (size_t)P->px[n.i] * NBF[n.i - 1] * P->es; }
-    if (plane > max_dy) max_dy = plane;
+    if (n.up_slot >= 0) n.up = bump(cur, (size_t)P->px[n.i] * NBF[n.i + 1] * P->es);
+    if (n.in_prefix == 0 && n.i > 0) n.pin = bump(cur, (size_t)P->px[n.i] * NBF[n.i - 1] * P->es);
   }
-  P->off_dy = bump(cur, max_dy);
-  P->off_da1 = bump(cur, max_dy);
-  P->off_gup = bump(cur, max_gup ? max_gup : 256);
-  P->off_gpin = bump(cur, max_gpin ? max_gpin : 256);
+  for (int i = 0; i < 5; ++i) {
+    const size_t plane = (size_t)P->px[i] * NBF[i] * P->es;
+    P->off_dy[i][0] = bump(cur, plane); P->off_dy[i][1] = bump(cur, plane);
+    P->off_da1[i] = bump(cur, plane);
+    P->off_gup[i] = bump(cur, i < 4 ? (size_t)P->px[i] * NBF[i + 1] * P->es : 256);
+    P->off_gpin[i] = bump(cur, i > 0 ? (size_t)P->px[i] * NBF[i - 1] * P->es : 256);
+  }
   P->total = align_up(cur, 256);
 
   // ---- pack / unpack tables ------------------------------------------------------
@@ -279,10 +297,35 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     UnpackEnt& ue = P->utab.e[P->utab.n++];
     ue.src = P->heads[k].gs; ue.dst = P->heads[k].w_off; ue.cout = cfg->num_classes; ue.cin = NBF[0]; ue.cinpad = NBF[0]; ue.taps = 1; ue.nvec = 1;
   }
+  PlanRt* rt = new PlanRt();
+  rt->lanes_ok = true;
+  rt->lanes_external = false;
+  rt->cap_next = 0;
+  rt->events_used[0] = rt->events_used[1] = 0;
+  { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
+  for (int l = 0; l < NLANES; ++l) {
+    rt->lanes[l] = nullptr;
+    if (hipStreamCreateWithFlags(&rt->lanes[l], hipStreamNonBlocking) != hipSuccess) { rt->lanes_ok = false; (void)hipGetLastError(); }
+  }
+  P->rt = rt;
   return P;
 }
 
-extern "C" void nunet_plan_destroy(nunet_plan* p) { delete p; }
+
+static PlanRt* rt_of(nunet_plan* P) { return P->rt; }
+
+extern "C" void nunet_plan_destroy(nunet_plan* p) {
+  if (!p) return;
+  if (p->rt) {
+    if (!p->rt->lanes_external)
+      for (int l = 0; l < NLANES; ++l) if (p->rt->lanes[l]) (void)hipStreamDestroy(p->rt->lanes[l]);
+    for (size_t k = 0; k < p->rt->cap_streams.size(); ++k) (void)hipStreamDestroy(p->rt->cap_streams[k]);
+    for (int q = 0; q < 2; ++q)
+      for (size_t k = 0; k < p->rt->events[q].size(); ++k) (void)hipEventDestroy(p->rt->events[q][k]);
+    delete p->rt;
+  }
+  delete p;
+}
 extern "C" size_t nunet_plan_arena_bytes(const nunet_plan* p) { return p ? p->total : 0; }
 extern "C" int64_t nunet_plan_param_count(const nunet_plan* p) { return p ? p->nparams : 0; }
 extern "C" int64_t nunet_plan_bnbuf_count(const nunet_plan* p) { return p ? p->nbnbuf : 0; }
@@ -307,6 +350,163 @@ extern "C" int64_t nunet_plan_feature(const nunet_plan* p, int32_t i, int32_t j,
 
 static inline char* AB(void* arena, size_t off) { return (char*)arena + off; }
 
+// ---------------------------------------------------------------------------
+// Lane scheduler. The x_{i,j} grid has natural concurrency: blocks of level i depend only
+// on levels i and i+-1, and weight gradients depend on nothing downstream. Every kernel
+// here is latency-bound on its own (short contractions, grid-starved deep levels), so the
+// plan issues level i on stream "lane i" (wgrad of level i on lane 5+i), forked from and
+// joined to the caller's stream with events. Exact RAW / WAW / WAR dependencies come from a
+// per-buffer tracker (last-writer event, last-reader event per lane). Captured by the
+// caller, the lanes become parallel branches of ONE hipGraph.
+// ---------------------------------------------------------------------------
+#define NRES 320
+enum { R_X = 0, R_GX = 25, R_BLK = 50, R_LVL = 180, R_IMG = 230, R_LOGITS = 231, R_DLOGITS = 232, R_GSW = 240, R_GSV = 280 };
+enum { B_Y1 = 0, B_A1, B_Y2, B_UP, B_PIN, B_ST1, B_ST2, B_STRIDE = 8 };
+enum { L_DY0 = 0, L_DY1, L_DA1, L_GUP, L_GPIN, L_STRIDE = 8 };
+
+struct Sched {
+  hipStream_t main_s;
+  hipStream_t lane_s[NLANES];      // stream currently carrying each lane (fixed lanes when not capturing)
+  hipEvent_t lane_tail[NLANES];    // event after the last op issued on the lane
+  bool multi, capturing, failed;
+  bool used[NLANES];
+  PlanRt* rt;
+  std::vector<hipEvent_t>* pool;
+  size_t* pool_used;
+  struct Res { hipEvent_t w_ev; hipStream_t w_st; hipEvent_t r_ev[NLANES]; hipStream_t r_st[NLANES]; };
+  Res res[NRES];
+  int cur_lane; int nreads, nwrites; int reads[16], writes[16];
+  hipEvent_t fork_ev;
+  hipEvent_t pend[64]; int npend;
+  int lane_map[NLANES];
+
+  hipEvent_t new_event() {
+    if (*pool_used == pool->size()) {
+      hipEvent_t e;
+      (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      pool->push_back(e);
+    }
+    return (*pool)[(*pool_used)++];
+  }
+  void init(nunet_plan* P, hipStream_t s, int pass);
+  // One wait per distinct event, never on an event of the stream itself.
+  void want(hipEvent_t ev, hipStream_t ev_st, hipStream_t st) {
+    if (!ev || ev_st == st) return;
+    for (int k = 0; k < npend; ++k) if (pend[k] == ev) return;
+    if (npend < 64) pend[npend++] = ev;
+  }
+  // ROCm 7.2: inside a stream capture, a stream that waits on an event DESCENDING from its
+  // own tail node crashes hipStreamEndCapture (tools/capture_patterns3.py "pp1"). The x_{i,j}
+  // grid ping-pongs between levels all the time, so while capturing a lane with cross-lane
+  // waits continues on a never-used stream that waits on the lane's tail event AND the
+  // cross-lane events (no own tail -> plain fork semantics). Eager issue keeps fixed lanes.
+  hipStream_t fresh_stream() {
+    if (rt->cap_next >= rt->cap_streams.size()) { failed = true; return nullptr; }
+    return rt->cap_streams[rt->cap_next++];
+  }
+  // begin an op on `lane` reading `rd` and writing `wr` resources; returns the stream to launch on
+  hipStream_t begin(int lane, std::initializer_list<int> rd, std::initializer_list<int> wr) {
+    if (!multi) return main_s;
+    lane = lane_map[lane];
+    cur_lane = lane; nreads = 0; nwrites = 0; npend = 0;
+    hipStream_t st = lane_s[lane];      // may be null while capturing (lane not started yet)
+    for (int r : rd) {
+      if (r < 0) continue;
+      reads[nreads++] = r;
+      Res& R = res[r];
+      want(R.w_ev, R.w_st, st);
+    }
+    for (int w : wr) {
+      if (w < 0) continue;
+      writes[nwrites++] = w;
+      Res& R = res[w];
+      want(R.w_ev, R.w_st, st);
+      for (int l = 0; l < NLANES; ++l) want(R.r_ev[l], R.r_st[l], st);
+    }
+    if (capturing) {
+      if (!used[lane] || npend > 0) {
+        hipStream_t ns = fresh_stream();
+        if (!ns) return main_s;   // pool exhausted: flagged, caller gets an error after the join
+        if (used[lane] && lane_tail[lane]) (void)hipStreamWaitEvent(ns, lane_tail[lane], 0);
+        else (void)hipStreamWaitEvent(ns, fork_ev, 0);
+        st = ns; lane_s[lane] = ns; used[lane] = true;
+      }
+    } else if (!used[lane]) {
+      used[lane] = true;
+      (void)hipStreamWaitEvent(st, fork_ev, 0);
+    }
+    for (int k = 0; k < npend; ++k) (void)hipStreamWaitEvent(st, pend[k], 0);
+    return st;
+  }
+  void end() {
+    if (!multi) return;
+    hipStream_t st = lane_s[cur_lane];
+    if (!st) return;
+    hipEvent_t ev = new_event();
+    (void)hipEventRecord(ev, st);
+    lane_tail[cur_lane] = ev;
+    for (int k = 0; k < nreads; ++k) { res[reads[k]].r_ev[cur_lane] = ev; res[reads[k]].r_st[cur_lane] = st; }
+    for (int k = 0; k < nwrites; ++k) {
+      Res& R = res[writes[k]];
+      R.w_ev = ev; R.w_st = st;
+      for (int l = 0; l < NLANES; ++l) { R.r_ev[l] = nullptr; R.r_st[l] = nullptr; }
+    }
+  }
+  void join() {
+    if (!multi) return;
+    for (int l = 0; l < NLANES; ++l)
+      if (used[l] && lane_tail[l]) (void)hipStreamWaitEvent(main_s, lane_tail[l], 0);
+  }
+};
+
+void Sched::init(nunet_plan* P, hipStream_t s, int pass) {
+  rt = rt_of(P);
+  main_s = s;
+  multi = rt->multistream != 0 && rt->lanes_ok;
+  failed = false;
+  capturing = false;
+  pool = &rt->events[pass]; pool_used = &rt->events_used[pass];
+  *pool_used = 0;
+  memset(res, 0, sizeof(res));
+  cur_lane = 0; nreads = nwrites = 0; npend = 0;
+  fork_ev = nullptr;
+  if (multi) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) capturing = true;
+    else (void)hipGetLastError();
+    if (!capturing && rt->cap_streams.empty()) {
+      // pool for later captures, created outside any capture (warm-up passes run eagerly first)
+      for (int k = 0; k < 320; ++k) {
+        hipStream_t q;
+        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        rt->cap_streams.push_back(q);
+      }
+    }
+    if (capturing && (rt->cap_streams.empty())) multi = false;     // never warmed up eagerly: stay on one stream
+    if (capturing && pass == 0) rt->cap_next = 0;                   // forward + backward of one capture share the pool
+  }
+  {
+    // NUNET_LANE_MAP: 10 digits, lane of (level 0..4, wgrad of level 0..4). Default "0123401234":
+    // one lane per pyramid level, weight gradients on their level's lane (measured best on MI355X:
+    // separate wgrad lanes add cross-queue edges that cost more than the overlap they buy).
+    const char* e = getenv("NUNET_LANE_MAP");
+    for (int l = 0; l < NLANES; ++l) lane_map[l] = (e && strlen(e) == NLANES && e[l] >= '0' && e[l] <= '9') ? e[l] - '0' : l % 5;
+  }
+  static int lane_mod = 0;
+  if (!lane_mod) { const char* e = getenv("NUNET_LANE_MOD"); lane_mod = e ? atoi(e) : NLANES; if (lane_mod < 1 || lane_mod > NLANES) lane_mod = NLANES; }
+  for (int l = 0; l < NLANES; ++l) { lane_s[l] = capturing ? nullptr : rt->lanes[l % lane_mod]; used[l] = false; lane_tail[l] = nullptr; }
+  if (multi) {
+    fork_ev = new_event();
+    (void)hipEventRecord(fork_ev, main_s);
+  }
+}
+
+static int blk_index(const nunet_plan* P, int i, int in_prefix_zero_only) {
+  for (size_t q = 0; q < P->exec.size(); ++q)
+    if (P->exec[q].i == i && (!in_prefix_zero_only || P->exec[q].in_prefix == 0)) return (int)q;
+  return -1;
+}
+
 extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnbuf, int64_t* nbt, const float* input, void* arena, float* logits, int32_t training, nunet_stream_t s) {
   NUNET_REQUIRE(P && params && input && arena && logits, "plan_forward: null pointer");
   NUNET_REQUIRE(bnbuf, "plan_forward: bnbuf (running stats) required");
@@ -316,41 +516,53 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   float* stats = (float*)AB(arena, P->off_stats);
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
-  if (training) {
-    CK(nunet_zero_async(stats, P->stats_floats * 4, st));
-  }
+  // prerequisites of everything on the caller's stream, before the fork
+  if (training) CK(nunet_zero_async(stats, P->stats_floats * 4, st));
   if (dt == NUNET_F32) CK(launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, st));
   else if (dt == NUNET_BF16) CK(launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, st));
   else CK(launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, st));
   CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, s));
 
-  for (size_t k = 0; k < P->exec.size(); ++k) {
+  Sched S; S.init(P, st, 0);
+  int rc = NUNET_OK;
+  for (size_t k = 0; k < P->exec.size() && rc == NUNET_OK; ++k) {
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
-    if (n.up_slot >= 0)
-      CK(nunet_upsample2x_fwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1],
-                              AB(arena, P->X[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1],
-                              AB(arena, n.up), NBF[i + 1], s));
-    for (int cv = 0; cv < 2; ++cv) {
+    const int lane = i, rb = R_BLK + (int)k * B_STRIDE;
+    if (n.up_slot >= 0) {
+      hipStream_t ls = S.begin(lane, {R_X + (i + 1) * 5 + n.up_slot}, {rb + B_UP});
+      rc = nunet_upsample2x_fwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1],
+                                AB(arena, P->X[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1],
+                                AB(arena, n.up), NBF[i + 1], ls);
+      S.end();
+      if (rc) break;
+    }
+    for (int cv = 0; cv < 2 && rc == NUNET_OK; ++cv) {
       const ConvL& L = cv == 0 ? n.c1 : n.c2;
       nunet_conv_desc d; memset(&d, 0, sizeof(d));
       d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
-      if (cv == 1) { d.src0 = AB(arena, n.a1); d.C0 = f; d.P0 = f; }
-      else if (n.in_prefix == 0) {
-        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; }
-        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; }
+      hipStream_t ls;
+      if (cv == 1) {
+        d.src0 = AB(arena, n.a1); d.C0 = f; d.P0 = f;
+        ls = S.begin(lane, {rb + B_A1}, {rb + B_Y2, rb + B_ST2});
+      } else if (n.in_prefix == 0) {
+        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG}, {rb + B_Y1, rb + B_ST1}); }
+        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN}, {rb + B_Y1, rb + B_ST1}); }
       } else {
         d.src0 = AB(arena, P->X[i]); d.C0 = n.in_prefix * f; d.P0 = P->PX[i];
         d.src1 = AB(arena, n.up); d.C1 = NBF[i + 1]; d.P1 = NBF[i + 1];
+        ls = S.begin(lane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
+                            n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP}, {rb + B_Y1, rb + B_ST1});
       }
       d.wpack = wpack + (size_t)L.wf * es;
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
       d.dst0 = AB(arena, cv == 0 ? n.y1 : n.y2); d.D0 = f; d.Q0 = f;
       d.stats = training ? stats + L.stats : nullptr;
       g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
-      const int rc_conv = nunet_conv3x3_fwd(&d, s);
+      rc = nunet_conv3x3_fwd(&d, ls);
       g_prof_alg_cin = 0;
-      CK(rc_conv);
+      S.end();
+      if (rc) break;
 
       nunet_bn_fwd_desc b; memset(&b, 0, sizeof(b));
       b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
@@ -359,22 +571,34 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       b.running_mean = bnbuf + L.rm_off; b.running_var = bnbuf + L.rv_off;
       b.num_batches_tracked = nbt ? nbt + L.bn_index : nullptr;
       b.save_mean_invstd = save + L.save; b.training = training; b.momentum = 0.1f; b.eps = 1e-5f;
-      if (cv == 0) { b.a = AB(arena, n.a1); b.PA = f; }
-      else {
+      if (cv == 0) {
+        b.a = AB(arena, n.a1); b.PA = f;
+        ls = S.begin(lane, {rb + B_Y1, rb + B_ST1}, {rb + B_A1});
+      } else {
         b.a = AB(arena, P->X[i] + (size_t)n.out_slot * f * es); b.PA = P->PX[i];
+        int rpin = -1;
         if (n.in_prefix == 0 && i < 4) {  // encoder column: feed the next level (archs1.py:115,118,122,127)
-          for (size_t q = 0; q < P->exec.size(); ++q)
-            if (P->exec[q].i == i + 1 && P->exec[q].in_prefix == 0) { b.pooled = AB(arena, P->exec[q].pin); b.PP = f; }
+          const int q = blk_index(P, i + 1, 1);
+          if (q >= 0) { b.pooled = AB(arena, P->exec[q].pin); b.PP = f; rpin = R_BLK + q * B_STRIDE + B_PIN; }
         }
+        ls = S.begin(lane, {rb + B_Y2, rb + B_ST2}, {R_X + i * 5 + n.out_slot, rpin});
       }
-      CK(nunet_bn_relu_fwd(&b, s));
+      rc = nunet_bn_relu_fwd(&b, ls);
+      S.end();
     }
   }
-  const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
-  for (size_t k = 0; k < P->heads.size(); ++k)
-    CK(nunet_head_fwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)P->heads[k].slot * NBF[0] * es), P->PX[0],
-                      params + P->heads[k].w_off, params + P->heads[k].b_off, logits + plane * k, s));
-  return NUNET_OK;
+  if (rc == NUNET_OK) {
+    const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
+    for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK; ++k) {
+      hipStream_t ls = S.begin(0, {R_X + P->heads[k].slot}, {R_LOGITS});
+      rc = nunet_head_fwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)P->heads[k].slot * NBF[0] * es), P->PX[0],
+                          params + P->heads[k].w_off, params + P->heads[k].b_off, logits + plane * k, ls);
+      S.end();
+    }
+  }
+  S.join();  // always rejoin the caller's stream (also on error: a capture must not be left forked)
+  if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_forward: capture lane pool exhausted"); rc = NUNET_EINVAL; }
+  return rc;
 }
 
 extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, nunet_stream_t s) {
@@ -388,83 +612,132 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
   char* wpack = AB(arena, P->off_wpack);
   CK(nunet_zero_async(gsr, P->gs_floats * 4, st));
   bool written[5][5]; memset(written, 0, sizeof(written));
+  int pp[5] = {0, 0, 0, 0, 0};   // per-level ping-pong of the dY scratch
 
+  Sched S; S.init(P, st, 1);
+  int rc = NUNET_OK;
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
-  for (size_t k = 0; k < P->heads.size(); ++k) {
+  for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK; ++k) {
     const Head& h = P->heads[k];
-    CK(nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
-                      params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
-                      written[0][h.slot] ? 1 : 0, gsr + h.gs, gsr + h.gs + (long long)c.num_classes * NBF[0], s));
+    hipStream_t ls = S.begin(0, {R_X + h.slot, R_DLOGITS}, {R_GX + h.slot, R_GSV + 30 + (int)k});
+    rc = nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
+                        params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
+                        written[0][h.slot] ? 1 : 0, gsr + h.gs, gsr + h.gs + (long long)c.num_classes * NBF[0], ls);
+    S.end();
     written[0][h.slot] = true;
   }
 
-  for (int k = (int)P->exec.size() - 1; k >= 0; --k) {
+  for (int k = (int)P->exec.size() - 1; k >= 0 && rc == NUNET_OK; --k) {
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
-    NUNET_REQUIRE(written[i][n.out_slot], "plan_backward: internal: grad of x%d_%d never produced", n.i, n.j);
-    for (int cv = 1; cv >= 0; --cv) {
+    const int lane = i, wlane = 5 + i, rb = R_BLK + k * B_STRIDE, rl = R_LVL + i * L_STRIDE;
+    if (!written[i][n.out_slot]) { nunet_set_error("plan_backward: internal: grad of x%d_%d never produced", n.i, n.j); rc = NUNET_EINVAL; break; }
+    for (int cv = 1; cv >= 0 && rc == NUNET_OK; --cv) {
       const ConvL& L = cv == 0 ? n.c1 : n.c2;
+      const int cidx = 2 * k + cv;
+      const int rdy = rl + (pp[i] ? L_DY1 : L_DY0);
+      char* dybuf = AB(arena, P->off_dy[i][pp[i]]);
+      pp[i] ^= 1;
       // BN + ReLU backward
       nunet_bn_bwd_desc b; memset(&b, 0, sizeof(b));
       b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
-      if (cv == 1) { b.da = AB(arena, P->GX[i] + (size_t)n.out_slot * f * es); b.PDA = P->PX[i]; b.y = AB(arena, n.y2); }
-      else { b.da = AB(arena, P->off_da1); b.PDA = f; b.y = AB(arena, n.y1); }
+      int rda, ry;
+      if (cv == 1) { b.da = AB(arena, P->GX[i] + (size_t)n.out_slot * f * es); b.PDA = P->PX[i]; b.y = AB(arena, n.y2); rda = R_GX + i * 5 + n.out_slot; ry = rb + B_Y2; }
+      else { b.da = AB(arena, P->off_da1[i]); b.PDA = f; b.y = AB(arena, n.y1); rda = rl + L_DA1; ry = rb + B_Y1; }
       b.PY = f; b.mean_invstd = save + L.save; b.gamma = params + L.g_off; b.beta = params + L.be_off;
       b.sums = bsums + L.bsum;
       float* gl = gsr + L.gs + 9LL * L.cout * L.cinpad;
       b.dbias = gl; b.dgamma = gl + L.cout; b.dbeta = gl + 2 * L.cout;
-      b.dy = AB(arena, P->off_dy); b.PDY = f;
-      CK(nunet_bn_relu_bwd_reduce(&b, s));
-      CK(nunet_bn_relu_bwd_apply(&b, s));
-      // wgrad
+      b.dy = dybuf; b.PDY = f;
+      hipStream_t ls = S.begin(lane, {rda, ry}, {rdy, R_GSV + cidx});
+      rc = nunet_bn_relu_bwd_reduce(&b, ls);
+      if (rc == NUNET_OK) rc = nunet_bn_relu_bwd_apply(&b, ls);
+      S.end();
+      if (rc) break;
+      // wgrad on the level's wgrad lane
       nunet_wgrad_desc w; memset(&w, 0, sizeof(w));
       w.dtype = dt; w.N = c.N; w.H = H; w.W = W;
-      if (cv == 1) { w.src0 = AB(arena, n.a1); w.C0 = f; w.P0 = f; }
-      else if (n.in_prefix == 0) {
-        if (i == 0) { w.src0 = AB(arena, P->off_img); w.C0 = 32; w.P0 = 32; }
-        else { w.src0 = AB(arena, n.pin); w.C0 = NBF[i - 1]; w.P0 = NBF[i - 1]; }
+      if (cv == 1) {
+        w.src0 = AB(arena, n.a1); w.C0 = f; w.P0 = f;
+        ls = S.begin(wlane, {rb + B_A1, rdy}, {R_GSW + cidx});
+      } else if (n.in_prefix == 0) {
+        if (i == 0) { w.src0 = AB(arena, P->off_img); w.C0 = 32; w.P0 = 32; ls = S.begin(wlane, {R_IMG, rdy}, {R_GSW + cidx}); }
+        else { w.src0 = AB(arena, n.pin); w.C0 = NBF[i - 1]; w.P0 = NBF[i - 1]; ls = S.begin(wlane, {rb + B_PIN, rdy}, {R_GSW + cidx}); }
       } else {
         w.src0 = AB(arena, P->X[i]); w.C0 = n.in_prefix * f; w.P0 = P->PX[i];
         w.src1 = AB(arena, n.up); w.C1 = NBF[i + 1]; w.P1 = NBF[i + 1];
+        ls = S.begin(wlane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
+                             n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, rdy}, {R_GSW + cidx});
       }
       w.dy = b.dy; w.Cout = f; w.PY = f; w.dw = gsr + L.gs;
       g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
-      const int rc_wg = nunet_conv3x3_wgrad(&w, s);
+      rc = nunet_conv3x3_wgrad(&w, ls);
       g_prof_alg_cin = 0;
-      CK(rc_wg);
+      S.end();
+      if (rc) break;
       // dgrad
       if (cv == 0 && i == 0 && n.in_prefix == 0) continue;  // no gradient into the image
       nunet_conv_desc d; memset(&d, 0, sizeof(d));
       d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
       d.src0 = b.dy; d.C0 = f; d.P0 = f;
       d.wpack = wpack + (size_t)L.wd * es;
-      if (cv == 1) { d.dst0 = AB(arena, P->off_da1); d.D0 = f; d.Q0 = f; }
-      else if (n.in_prefix == 0) { d.dst0 = AB(arena, P->off_gpin); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1]; }
-      else {
+      if (cv == 1) {
+        d.dst0 = AB(arena, P->off_da1[i]); d.D0 = f; d.Q0 = f;
+        ls = S.begin(lane, {rdy}, {rl + L_DA1});
+      } else if (n.in_prefix == 0) {
+        d.dst0 = AB(arena, P->off_gpin[i]); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1];
+        ls = S.begin(lane, {rdy}, {rl + L_GPIN});
+      } else {
         d.dst0 = AB(arena, P->GX[i]); d.D0 = n.in_prefix * f; d.Q0 = P->PX[i]; d.acc_slot_w = f;
         for (int q = 0; q < n.in_prefix; ++q) { if (written[i][q]) d.acc0_mask |= 1u << q; written[i][q] = true; }
-        d.dst1 = AB(arena, P->off_gup); d.D1 = NBF[i + 1]; d.Q1 = NBF[i + 1];
+        d.dst1 = AB(arena, P->off_gup[i]); d.D1 = NBF[i + 1]; d.Q1 = NBF[i + 1];
+        ls = S.begin(lane, {rdy}, {R_GX + i * 5 + 0, n.in_prefix > 1 ? R_GX + i * 5 + 1 : -1, n.in_prefix > 2 ? R_GX + i * 5 + 2 : -1,
+                                   n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP});
       }
-      CK(nunet_conv3x3_fwd(&d, s));
+      rc = nunet_conv3x3_fwd(&d, ls);
+      S.end();
+      if (rc) break;
       if (cv == 0) {
         if (n.in_prefix == 0) {
           // through MaxPool2d(2,2) into x_{i-1,0}
-          CK(nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
-                                  AB(arena, P->off_gpin), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], written[i - 1][0] ? 1 : 0, s));
+          ls = S.begin(lane, {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0});
+          rc = nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
+                                    AB(arena, P->off_gpin[i]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], written[i - 1][0] ? 1 : 0, ls);
+          S.end();
           written[i - 1][0] = true;
         } else {
           // through the bilinear upsample into x_{i+1,up_slot}
-          CK(nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup), NBF[i + 1],
-                                  AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], written[i + 1][n.up_slot] ? 1 : 0, s));
+          ls = S.begin(lane, {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot});
+          rc = nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[i]), NBF[i + 1],
+                                    AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], written[i + 1][n.up_slot] ? 1 : 0, ls);
+          S.end();
           written[i + 1][n.up_slot] = true;
         }
       }
     }
   }
+  S.join();
+  if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_backward: capture lane pool exhausted"); rc = NUNET_EINVAL; }
+  if (rc) return rc;
   P->utab.accumulate = accumulate;
   int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
   if (gx > 512) gx = 512;
   ProfScope ps(PC_UNPACK, 0, (double)P->nparams * (accumulate ? 12 : 8), st);
   hipLaunchKernelGGL(unpack_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, gsr, grads, P->utab);
   return nunet_check_launch("unpack_grads");
+}
+
+extern "C" int nunet_plan_set_lanes(nunet_plan* P, nunet_stream_t* lanes, int32_t n) {
+  NUNET_REQUIRE(P && lanes && n >= 1, "plan_set_lanes: bad args");
+  PlanRt* rt = rt_of(P);
+  for (int l = 0; l < NLANES; ++l) rt->lanes[l] = (hipStream_t)lanes[l % n];   // caller-owned streams
+  rt->lanes_ok = true;
+  rt->lanes_external = true;
+  return NUNET_OK;
+}
+
+extern "C" int nunet_plan_set_multistream(nunet_plan* P, int32_t enable) {
+  NUNET_REQUIRE(P, "plan_set_multistream: null plan");
+  rt_of(P)->multistream = enable;
+  return NUNET_OK;
 }
