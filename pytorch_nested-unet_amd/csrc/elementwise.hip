@@ -137,12 +137,25 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   const int pl = threadIdx.x / G;
   if constexpr (!POOL) {
     const int64_t npix = (int64_t)p.N * p.H * p.W;
-    for (int64_t pix = (int64_t)blockIdx.x * ppb + pl; pix < npix; pix += (int64_t)gridDim.x * ppb) {
-      Vec16<T> v = ld16((const T*)p.y + pix * p.PY + cg * EPV);
-      Vec16<T> o;
+    const int64_t stride = (int64_t)gridDim.x * ppb;
+    constexpr int U = 4;   // 16-byte loads kept in flight per thread
+    for (int64_t pix0 = (int64_t)blockIdx.x * ppb + pl; pix0 < npix; pix0 += U * stride) {
+      Vec16<T> v[U];
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) o.set(e, fmaxf(v.get(e) * sc[e] + sh[e], 0.f));
-      st16((T*)p.a + pix * p.PA + cg * EPV, o);
+      for (int u = 0; u < U; ++u) {
+        const int64_t pix = pix0 + u * stride;
+        if (pix < npix) v[u] = ld16((const T*)p.y + pix * p.PY + cg * EPV);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t pix = pix0 + u * stride;
+        if (pix < npix) {
+          Vec16<T> o;
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) o.set(e, fmaxf(v[u].get(e) * sc[e] + sh[e], 0.f));
+          st16((T*)p.a + pix * p.PA + cg * EPV, o);
+        }
+      }
     }
   } else {
     const int H2 = p.H / 2, W2 = p.W / 2;
@@ -247,26 +260,41 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
 #pragma unroll
   for (int e = 0; e < EPV; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
   const int64_t npix = (int64_t)p.N * p.H * p.W;
-  for (int64_t pix = (int64_t)blockIdx.x * ppb + pl; pix < npix; pix += (int64_t)gridDim.x * ppb) {
-    const Vec16<T> vy = ld16((const T*)p.y + pix * p.PY + cg * EPV);
-    const Vec16<T> vd = ld16((const T*)p.da + pix * p.PDA + cg * EPV);
-    Vec16<T> o;
+  const int64_t stride = (int64_t)gridDim.x * ppb;
+  constexpr int U = 4;   // pixels per thread per iteration: 8 sixteen-byte loads in flight
+  for (int64_t pix0 = (int64_t)blockIdx.x * ppb + pl; pix0 < npix; pix0 += U * stride) {
+    Vec16<T> vy[U], vd[U];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      const float yv = vy.get(e);
-      const float act = yv * sc[e] + sh[e];
-      const float dz = act > 0.f ? vd.get(e) : 0.f;
-      const float xh = (yv - mean[e]) * istd[e];
-      if constexpr (APPLY) {
-        const float dyv = sc[e] * (dz - k1[e] - xh * k2[e]);
-        o.set(e, dyv);
-        a1[e] += o.get(e);
-      } else {
-        a1[e] += dz;
-        a2[e] += dz * xh;
+    for (int u = 0; u < U; ++u) {
+      const int64_t pix = pix0 + u * stride;
+      if (pix < npix) {
+        vy[u] = ld16((const T*)p.y + pix * p.PY + cg * EPV);
+        vd[u] = ld16((const T*)p.da + pix * p.PDA + cg * EPV);
       }
     }
-    if constexpr (APPLY) st16((T*)p.dy + pix * p.PDY + cg * EPV, o);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pix = pix0 + u * stride;
+      if (pix < npix) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const float yv = vy[u].get(e);
+          const float act = yv * sc[e] + sh[e];
+          const float dz = act > 0.f ? vd[u].get(e) : 0.f;
+          const float xh = (yv - mean[e]) * istd[e];
+          if constexpr (APPLY) {
+            const float dyv = sc[e] * (dz - k1[e] - xh * k2[e]);
+            o.set(e, dyv);
+            a1[e] += o.get(e);
+          } else {
+            a1[e] += dz;
+            a2[e] += dz * xh;
+          }
+        }
+        if constexpr (APPLY) st16((T*)p.dy + pix * p.PDY + cg * EPV, o);
+      }
+    }
   }
   // block reduction over the ppb threads that share a channel group, then one atomic per channel
 #pragma unroll

@@ -632,6 +632,7 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
     const int lane = i, wlane = 5 + i, rb = R_BLK + k * B_STRIDE, rl = R_LVL + i * L_STRIDE;
     if (!written[i][n.out_slot]) { nunet_set_error("plan_backward: internal: grad of x%d_%d never produced", n.i, n.j); rc = NUNET_EINVAL; break; }
+    nunet_wgrad_desc wdesc[2]; int wrdy[2] = {-1, -1};
     for (int cv = 1; cv >= 0 && rc == NUNET_OK; --cv) {
       const ConvL& L = cv == 0 ? n.c1 : n.c2;
       const int cidx = 2 * k + cv;
@@ -654,27 +655,20 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
       if (rc == NUNET_OK) rc = nunet_bn_relu_bwd_apply(&b, ls);
       S.end();
       if (rc) break;
-      // wgrad on the level's wgrad lane
-      nunet_wgrad_desc w; memset(&w, 0, sizeof(w));
+      // weight gradient: prepared here, issued after the block's dgrad chain (below) so that
+      // the levels waiting on this block's input gradients start earlier
+      nunet_wgrad_desc& w = wdesc[cv]; memset(&w, 0, sizeof(w));
       w.dtype = dt; w.N = c.N; w.H = H; w.W = W;
-      if (cv == 1) {
-        w.src0 = AB(arena, n.a1); w.C0 = f; w.P0 = f;
-        ls = S.begin(wlane, {rb + B_A1, rdy}, {R_GSW + cidx});
-      } else if (n.in_prefix == 0) {
-        if (i == 0) { w.src0 = AB(arena, P->off_img); w.C0 = 32; w.P0 = 32; ls = S.begin(wlane, {R_IMG, rdy}, {R_GSW + cidx}); }
-        else { w.src0 = AB(arena, n.pin); w.C0 = NBF[i - 1]; w.P0 = NBF[i - 1]; ls = S.begin(wlane, {rb + B_PIN, rdy}, {R_GSW + cidx}); }
+      if (cv == 1) { w.src0 = AB(arena, n.a1); w.C0 = f; w.P0 = f; }
+      else if (n.in_prefix == 0) {
+        if (i == 0) { w.src0 = AB(arena, P->off_img); w.C0 = 32; w.P0 = 32; }
+        else { w.src0 = AB(arena, n.pin); w.C0 = NBF[i - 1]; w.P0 = NBF[i - 1]; }
       } else {
         w.src0 = AB(arena, P->X[i]); w.C0 = n.in_prefix * f; w.P0 = P->PX[i];
         w.src1 = AB(arena, n.up); w.C1 = NBF[i + 1]; w.P1 = NBF[i + 1];
-        ls = S.begin(wlane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
-                             n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, rdy}, {R_GSW + cidx});
       }
       w.dy = b.dy; w.Cout = f; w.PY = f; w.dw = gsr + L.gs;
-      g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
-      rc = nunet_conv3x3_wgrad(&w, ls);
-      g_prof_alg_cin = 0;
-      S.end();
-      if (rc) break;
+      wrdy[cv] = rdy;
       // dgrad
       if (cv == 0 && i == 0 && n.in_prefix == 0) continue;  // no gradient into the image
       nunet_conv_desc d; memset(&d, 0, sizeof(d));
@@ -714,6 +708,18 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
           written[i + 1][n.up_slot] = true;
         }
       }
+    }
+    for (int cv = 1; cv >= 0 && rc == NUNET_OK; --cv) {
+      const int cidx = 2 * k + cv;
+      hipStream_t ls;
+      if (cv == 1) ls = S.begin(wlane, {rb + B_A1, wrdy[cv]}, {R_GSW + cidx});
+      else if (n.in_prefix == 0) ls = S.begin(wlane, {i == 0 ? R_IMG : rb + B_PIN, wrdy[cv]}, {R_GSW + cidx});
+      else ls = S.begin(wlane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
+                                n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, wrdy[cv]}, {R_GSW + cidx});
+      g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
+      rc = nunet_conv3x3_wgrad(&wdesc[cv], ls);
+      g_prof_alg_cin = 0;
+      S.end();
     }
   }
   S.join();
