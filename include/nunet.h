@@ -163,6 +163,14 @@ int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int6
 /* dlogits = gscale[0] * dloss/dlogits */
 int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per_sample,
                        const float* ws, const float* gscale, float* dlogits, nunet_stream_t s);
+/* Fused loss step of the training loop (trains.py:118-128,135-136): BCEDice of every head,
+ * dlogits of their mean, IoU counts of the last head. logits/dlogits: [heads][N][per].
+ * loss_out: [heads+1] (per head, then the mean). meters (may be NULL): double[4]:
+ * [0] += mean loss, [1] += IoU of this batch, [2],[3] = intersection / union counts. */
+size_t nunet_loss_step_ws_bytes(int32_t N, int32_t heads);
+int nunet_loss_step(const float* logits, const float* target, int32_t N, int64_t per_sample,
+                    int32_t heads, float* ws, float* dlogits, float* loss_out, double* meters,
+                    nunet_stream_t s);
 /* counts[0] += |A&B|, counts[1] += |A|B|, A = logits>0, B = target>0.5 */
 int nunet_iou_counts(const float* logits, const float* target, int64_t n,
                      unsigned long long* counts, nunet_stream_t s);

@@ -733,6 +733,93 @@ extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int3
 }
 
 // ---------------------------------------------------------------------------
+// Fused loss step of the training loop (trains.py:118-128,135-136): all heads' BCEDice
+// partial sums + IoU counts of the last head in one launch; then gradients of the
+// head-averaged loss, the loss values and the running epoch meters in a second one.
+// ws: [heads][3N+1] sums (row stride ws_stride floats) followed by 2 x uint64 IoU counts.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_step_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, float* __restrict__ ws, int ws_stride, int N, int heads) {
+  const int n = blockIdx.y, hd = blockIdx.z;
+  const float* xs = x + ((int64_t)hd * N + n) * per;
+  const float* ts = t + (int64_t)n * per;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  unsigned ci = 0, cu = 0;
+  const bool last = hd == heads - 1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = xs[i], tv = ts[i];
+    const float pv = sigmoidf_(xv);
+    a0 += pv * tv; a1 += pv; a2 += tv;
+    a3 += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
+    if (last) { const bool a = xv > 0.f, b = tv > 0.5f; ci += (a && b) ? 1u : 0u; cu += (a || b) ? 1u : 0u; }
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o); cu += __shfl_xor(cu, o); }
+  if ((threadIdx.x & 63) == 0) {
+    float* w = ws + (size_t)hd * ws_stride;
+    atomicAdd(&w[n * 3 + 0], a0); atomicAdd(&w[n * 3 + 1], a1); atomicAdd(&w[n * 3 + 2], a2); atomicAdd(&w[N * 3], a3);
+    if (last) {
+      unsigned long long* cnt = (unsigned long long*)(ws + (size_t)heads * ws_stride);
+      atomicAdd(&cnt[0], (unsigned long long)ci); atomicAdd(&cnt[1], (unsigned long long)cu);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void loss_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, const float* __restrict__ ws, int ws_stride, int N, int heads, float* __restrict__ dx, float* __restrict__ loss_out, double* __restrict__ meters) {
+  const int n = blockIdx.y, hd = blockIdx.z;
+  const float* w = ws + (size_t)hd * ws_stride;
+  if (blockIdx.x == 0 && n == 0 && hd == 0 && threadIdx.x == 0) {
+    // loss per head, their mean (trains.py:120-123), IoU of the last head (trains.py:124,128)
+    float mean = 0.f;
+    for (int k = 0; k < heads; ++k) {
+      const float* wk = ws + (size_t)k * ws_stride;
+      float d = 0.f;
+      for (int q = 0; q < N; ++q) d += (2.f * wk[q * 3] + 1e-5f) / (wk[q * 3 + 1] + wk[q * 3 + 2] + 1e-5f);
+      const float l = 0.5f * wk[N * 3] / ((float)N * (float)per) + (1.f - d / (float)N);
+      loss_out[k] = l;
+      mean += l;
+    }
+    mean /= (float)heads;
+    loss_out[heads] = mean;
+    const unsigned long long* cnt = (const unsigned long long*)(ws + (size_t)heads * ws_stride);
+    if (meters) {
+      meters[0] += (double)mean;
+      meters[1] += ((double)cnt[0] + 1e-5) / ((double)cnt[1] + 1e-5);
+      meters[2] = (double)cnt[0]; meters[3] = (double)cnt[1];
+    }
+  }
+  const float I = w[n * 3], D = w[n * 3 + 1] + w[n * 3 + 2] + 1e-5f;
+  const float g = 1.f / (float)heads;
+  const float kb = 0.5f / ((float)N * (float)per);
+  const float num = 2.f * I + 1e-5f;
+  const float invD2 = 1.f / (D * D);
+  const float invN = 1.f / (float)N;
+  const float* xs = x + ((int64_t)hd * N + n) * per;
+  const float* ts = t + (int64_t)n * per;
+  float* ds = dx + ((int64_t)hd * N + n) * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = xs[i], tv = ts[i];
+    const float pv = sigmoidf_(xv);
+    const float ddice = (2.f * tv * D - num) * invD2 * pv * (1.f - pv);
+    ds[i] = g * (kb * (pv - tv) - invN * ddice);
+  }
+}
+extern "C" size_t nunet_loss_step_ws_bytes(int32_t N, int32_t heads) {
+  const size_t stride = ((size_t)(3 * N + 1) + 3) / 4 * 4;
+  return (stride * heads + 4) * sizeof(float);
+}
+extern "C" int nunet_loss_step(const float* logits, const float* target, int32_t N, int64_t per, int32_t heads, float* ws, float* dlogits, float* loss_out, double* meters, nunet_stream_t s) {
+  NUNET_REQUIRE(logits && target && ws && dlogits && loss_out && N > 0 && per > 0 && heads >= 1 && heads <= 8, "loss_step: bad args");
+  hipStream_t st = (hipStream_t)s;
+  const int stride = (3 * N + 1 + 3) / 4 * 4;
+  { int rc = nunet_zero_async(ws, nunet_loss_step_ws_bytes(N, heads), st); if (rc) return rc; }
+  const int gx = grid_for(per, 256 * 4, 64);
+  ProfScope ps(PC_LOSS, 0, (double)N * per * heads * 16, st);
+  hipLaunchKernelGGL(loss_step_partial_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, stride, N, heads);
+  hipLaunchKernelGGL(loss_step_bwd_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, stride, N, heads, dlogits, loss_out, meters);
+  return nunet_check_launch("loss_step");
+}
+
+// ---------------------------------------------------------------------------
 // iou_score counts (metrics.py:10-14): sigmoid(x) > 0.5  <=>  x > 0
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n, unsigned long long* __restrict__ counts) {

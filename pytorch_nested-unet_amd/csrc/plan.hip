@@ -22,32 +22,44 @@ static const int NBF[5] = {32, 64, 128, 256, 512};  // archs1.py:78
 // ---------------------------------------------------------------------------
 #define MAXENT 40
 struct PackEnt { long long src, wf, wd; int cout, cin, cinpad, pad_; };
-struct PackTab { int n; int pad_; PackEnt e[MAXENT]; };
+struct PackTab { int n; int ntiles; PackEnt e[MAXENT]; int tile0[MAXENT + 1]; };
 struct UnpackEnt { long long src, dst; int cout, cin, cinpad, taps, nvec, pad_; };
 struct UnpackTab { int n; int accumulate; UnpackEnt e[MAXENT]; };
 
+// One block per (layer, 32 Cout x 32 Cin tile): the OIHW rows of a tile are contiguous runs of
+// 32*9 floats (coalesced loads into LDS); both packed layouts are then written as contiguous
+// 32-element rows. PackTab carries a prefix sum of tiles per entry for the block -> tile map.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ params, T* __restrict__ arena, PackTab tab) {
-  const PackEnt en = tab.e[blockIdx.y];
+  __shared__ float s_t[32][32 * 9 + 1];
+  int e = 0;
+  while (e + 1 < tab.n && (int)blockIdx.x >= tab.tile0[e + 1]) ++e;
+  const PackEnt en = tab.e[e];
+  const int t = blockIdx.x - tab.tile0[e];
+  const int nci = (en.cinpad + 31) / 32;
+  const int co0 = (t / nci) * 32, ci0 = (t % nci) * 32;
   const float* w = params + en.src;
-  const long long nf = 9LL * en.cout * en.cinpad;
+  const int cw = min(32, en.cin - ci0);            // real input channels in this tile (<= 0: pure padding)
+  const int rw = min(32, en.cout - co0);
+  for (int i = threadIdx.x; i < 32 * 288; i += blockDim.x) {
+    const int ro = i / 288, k = i - ro * 288;      // k = ci_local*9 + tap
+    float v = 0.f;
+    if (ro < rw && k < cw * 9) v = w[((long long)(co0 + ro) * en.cin + ci0) * 9 + k];
+    s_t[ro][k] = v;
+  }
+  __syncthreads();
   T* wf = arena + en.wf;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf; i += (long long)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % en.cinpad);
-    const long long t = i / en.cinpad;
-    const int co = (int)(t % en.cout);
-    const int tap = (int)(t / en.cout);
-    wf[i] = from_f32<T>(ci < en.cin ? w[((long long)co * en.cin + ci) * 9 + tap] : 0.f);
+  for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) {   // wf[tap][co][ci], ci fastest
+    const int ci = i & 31, ro = (i >> 5) & 31, tap = i >> 10;
+    if (ro < rw && ci0 + ci < en.cinpad)
+      wf[((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + ci] = from_f32<T>(s_t[ro][ci * 9 + tap]);
   }
   if (en.wd >= 0) {
     T* wd = arena + en.wd;
-    const long long nd = 9LL * en.cout * en.cin;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nd; i += (long long)gridDim.x * blockDim.x) {
-      const int co = (int)(i % en.cout);
-      const long long t = i / en.cout;
-      const int ci = (int)(t % en.cin);
-      const int tap = (int)(t / en.cin);
-      wd[i] = from_f32<T>(w[((long long)co * en.cin + ci) * 9 + (8 - tap)]);
+    for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) { // wd[8-tap][ci][co], co fastest
+      const int ro = i & 31, ci = (i >> 5) & 31, tap = i >> 10;
+      if (ro < rw && ci < cw)
+        wd[((long long)(8 - tap) * en.cin + ci0 + ci) * en.cout + co0 + ro] = from_f32<T>(s_t[ro][ci * 9 + tap]);
     }
   }
 }
@@ -73,14 +85,15 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
   }
 }
 
-template <typename T> static int launch_pack(const float* params, void* arena_t, const PackTab& tab, long long maxn, hipStream_t st) {
-  int gx = (int)ceil_div64(maxn, 256 * 4);
-  if (gx > 512) gx = 512;
-  if (gx < 1) gx = 1;
+template <typename T> static int launch_pack(const float* params, void* arena_t, PackTab& tab, long long maxn, hipStream_t st) {
+  (void)maxn;
+  int nt = 0;
+  for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
+  tab.tile0[tab.n] = nt; tab.ntiles = nt;
   double pb = 0;
   for (int i = 0; i < tab.n; ++i) pb += 9.0 * tab.e[i].cout * tab.e[i].cin * (4 + (tab.e[i].wd >= 0 ? 2 : 1) * sizeof(T));
   ProfScope ps(PC_PACK, 0, pb, st);
-  hipLaunchKernelGGL((pack_kernel<T>), dim3(gx, tab.n), dim3(256), 0, st, params, (T*)arena_t, tab);
+  hipLaunchKernelGGL((pack_kernel<T>), dim3(nt), dim3(256), 0, st, params, (T*)arena_t, tab);
   return nunet_check_launch("pack_weights");
 }
 
@@ -142,6 +155,7 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   bool lanes_external;
   std::vector<hipStream_t> cap_streams;   // never-reused streams for capture-time lane continuation
   size_t cap_next;
+  void* gs_clean_arena;   // arena whose gradient scratch was cleared by the last training forward
 };
 struct nunet_plan;
 static PlanRt* rt_of(nunet_plan* P);
@@ -165,6 +179,7 @@ struct nunet_plan {
   struct PlanRt* rt;
   size_t total;
   PackTab ptab; long long pack_maxn;
+  PackTab ptab_lvl[5]; long long pack_maxn_lvl[5];   // the same entries grouped by pyramid level (issued per lane)
   UnpackTab utab; long long unpack_maxn;
 };
 
@@ -293,6 +308,17 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     if (9LL * c.cout * c.cin + 3 * c.cout > P->unpack_maxn) P->unpack_maxn = 9LL * c.cout * c.cin + 3 * c.cout;
   };
   for (size_t r = 0; r < P->reg.size(); ++r) { add_conv(P->exec[P->reg[r]].c1); add_conv(P->exec[P->reg[r]].c2); }
+  for (int l = 0; l < 5; ++l) { memset(&P->ptab_lvl[l], 0, sizeof(PackTab)); P->pack_maxn_lvl[l] = 0; }
+  for (size_t k = 0; k < P->exec.size(); ++k) {
+    const Node& n = P->exec[k];
+    for (int cv = 0; cv < 2; ++cv) {
+      const ConvL& c = cv ? n.c2 : n.c1;
+      PackTab& t = P->ptab_lvl[n.i];
+      PackEnt& pe = t.e[t.n++];
+      pe.src = c.w_off; pe.wf = c.wf; pe.wd = c.wd; pe.cout = c.cout; pe.cin = c.cin; pe.cinpad = c.cinpad;
+      if (9LL * c.cout * c.cinpad > P->pack_maxn_lvl[n.i]) P->pack_maxn_lvl[n.i] = 9LL * c.cout * c.cinpad;
+    }
+  }
   for (size_t k = 0; k < P->heads.size(); ++k) {
     UnpackEnt& ue = P->utab.e[P->utab.n++];
     ue.src = P->heads[k].gs; ue.dst = P->heads[k].w_off; ue.cout = cfg->num_classes; ue.cin = NBF[0]; ue.cinpad = NBF[0]; ue.taps = 1; ue.nvec = 1;
@@ -301,6 +327,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->lanes_ok = true;
   rt->lanes_external = false;
   rt->cap_next = 0;
+  rt->gs_clean_arena = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
   { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
   for (int l = 0; l < NLANES; ++l) {
@@ -360,7 +387,7 @@ static inline char* AB(void* arena, size_t off) { return (char*)arena + off; }
 // caller, the lanes become parallel branches of ONE hipGraph.
 // ---------------------------------------------------------------------------
 #define NRES 320
-enum { R_X = 0, R_GX = 25, R_BLK = 50, R_LVL = 180, R_IMG = 230, R_LOGITS = 231, R_DLOGITS = 232, R_GSW = 240, R_GSV = 280 };
+enum { R_X = 0, R_GX = 25, R_BLK = 50, R_LVL = 180, R_IMG = 230, R_LOGITS = 231, R_DLOGITS = 232, R_WP = 233, R_GS = 238, R_GSW = 240, R_GSV = 280 };
 enum { B_Y1 = 0, B_A1, B_Y2, B_UP, B_PIN, B_ST1, B_ST2, B_STRIDE = 8 };
 enum { L_DY0 = 0, L_DY1, L_DA1, L_GUP, L_GPIN, L_STRIDE = 8 };
 
@@ -518,13 +545,37 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   char* wpack = AB(arena, P->off_wpack);
   // prerequisites of everything on the caller's stream, before the fork
   if (training) CK(nunet_zero_async(stats, P->stats_floats * 4, st));
-  if (dt == NUNET_F32) CK(launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, st));
-  else if (dt == NUNET_BF16) CK(launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, st));
-  else CK(launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, st));
   CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, s));
 
   Sched S; S.init(P, st, 0);
   int rc = NUNET_OK;
+  // Measured on MI355X: repacking the weights per level on the lanes (NUNET_PACK_LANES=1) is 9 %
+  // SLOWER than one pack launch ahead of the lanes; clearing the gradient scratch on a lane during
+  // forward (NUNET_GS_FWD=1) is neutral. Both stay off by default.
+  static int pack_lanes = -1, gs_fwd = -1;
+  if (pack_lanes < 0) { const char* e = getenv("NUNET_PACK_LANES"); pack_lanes = e ? atoi(e) : 0; e = getenv("NUNET_GS_FWD"); gs_fwd = e ? atoi(e) : 0; }
+  if (!pack_lanes) {
+    hipStream_t ls = S.begin(0, {}, {R_WP + 0, R_WP + 1, R_WP + 2, R_WP + 3, R_WP + 4});
+    if (dt == NUNET_F32) rc = launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, ls);
+    else if (dt == NUNET_BF16) rc = launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
+    else rc = launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
+    S.end();
+  }
+  for (int l = 0; l < 5 && rc == NUNET_OK && pack_lanes; ++l) {
+    if (P->ptab_lvl[l].n == 0) continue;
+    hipStream_t ls = S.begin(l, {}, {R_WP + l});
+    if (dt == NUNET_F32) rc = launch_pack<float>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);
+    else if (dt == NUNET_BF16) rc = launch_pack<bf16_t>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);
+    else rc = launch_pack<f16_t>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);
+    S.end();
+  }
+  if (training && rc == NUNET_OK && gs_fwd) {
+    // the gradient scratch of the coming backward is cleared here, on the least loaded lane
+    hipStream_t ls = S.begin(4, {}, {R_GS});
+    rc = nunet_zero_async(AB(arena, P->off_gs), P->gs_floats * 4, ls);
+    S.end();
+    rt_of(P)->gs_clean_arena = arena;
+  }
   for (size_t k = 0; k < P->exec.size() && rc == NUNET_OK; ++k) {
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
@@ -544,15 +595,15 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       hipStream_t ls;
       if (cv == 1) {
         d.src0 = AB(arena, n.a1); d.C0 = f; d.P0 = f;
-        ls = S.begin(lane, {rb + B_A1}, {rb + B_Y2, rb + B_ST2});
+        ls = S.begin(lane, {rb + B_A1, R_WP + i}, {rb + B_Y2, rb + B_ST2});
       } else if (n.in_prefix == 0) {
-        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG}, {rb + B_Y1, rb + B_ST1}); }
-        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN}, {rb + B_Y1, rb + B_ST1}); }
+        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG, R_WP + i}, {rb + B_Y1, rb + B_ST1}); }
+        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN, R_WP + i}, {rb + B_Y1, rb + B_ST1}); }
       } else {
         d.src0 = AB(arena, P->X[i]); d.C0 = n.in_prefix * f; d.P0 = P->PX[i];
         d.src1 = AB(arena, n.up); d.C1 = NBF[i + 1]; d.P1 = NBF[i + 1];
         ls = S.begin(lane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
-                            n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP}, {rb + B_Y1, rb + B_ST1});
+                            n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, R_WP + i}, {rb + B_Y1, rb + B_ST1});
       }
       d.wpack = wpack + (size_t)L.wf * es;
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
@@ -610,7 +661,8 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
   float* bsums = gsr + (P->gs_floats - P->stats_floats);
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
-  CK(nunet_zero_async(gsr, P->gs_floats * 4, st));
+  if (rt_of(P)->gs_clean_arena == arena) rt_of(P)->gs_clean_arena = nullptr;   // cleared by the forward that produced the activations
+  else CK(nunet_zero_async(gsr, P->gs_floats * 4, st));
   bool written[5][5]; memset(written, 0, sizeof(written));
   int pp[5] = {0, 0, 0, 0, 0};   // per-level ping-pong of the dY scratch
 

@@ -35,17 +35,13 @@ class TrainStep:
         self.logits = torch.empty((self.heads, n, self.ncls, h, w), dtype=torch.float32, device=dev)
         self.dlogits = torch.empty_like(self.logits)
         self.per = self.ncls * h * w
-        self.ws_stride = (3 * n + 1 + 3) // 4 * 4          # 16-byte aligned rows (zeroed by nunet_zero_async)
-        self.loss_ws = torch.empty((self.heads, self.ws_stride), dtype=torch.float32, device=dev)
-        self.loss_heads = torch.zeros(self.heads, dtype=torch.float32, device=dev)
-        self.gscale = torch.full((1,), 1.0 / self.heads, dtype=torch.float32, device=dev)
+        self.loss_ws = torch.empty(L.lib().nunet_loss_step_ws_bytes(n, self.heads) // 4, dtype=torch.float32, device=dev)
+        self.loss_out = torch.zeros(self.heads + 1, dtype=torch.float32, device=dev)   # per head, then their mean
+        # device-side epoch meters: [sum of step losses, sum of step IoUs, last intersection, last union]
+        self.meters = torch.zeros(4, dtype=torch.float64, device=dev)
         self.lr = torch.full((1,), lr, dtype=torch.float32, device=dev)
         self.mom = torch.zeros_like(self.eng.flat_params)
         self.momentum, self.wd, self.nesterov = momentum, weight_decay, nesterov
-        # running sums for the epoch meters: sum of per-step loss, steps, IoU numer/denom per step
-        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.iou_counts = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.iou_sum = torch.zeros(1, dtype=torch.float64, device=dev)
         self.steps = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
@@ -61,24 +57,10 @@ class TrainStep:
         st = L.stream()
         L.check(lib.nunet_plan_forward(pl.handle, L.ptr(eng.flat_params), L.ptr(eng.bnbuf), L.ptr(eng.nbt),
                                        L.ptr(self.x), L.ptr(pl.arena), L.ptr(self.logits), 1, st), "plan_forward")
-        plane = self.n * self.per * 4
-        for k in range(self.heads):
-            L.check(lib.nunet_bce_dice_fwd(L.ptr(self.logits, k * plane), L.ptr(self.t), self.n, self.per,
-                                           L.ptr(self.loss_ws, k * self.ws_stride * 4), L.ptr(self.loss_heads, 4 * k), st),
-                    "bce_dice_fwd")
-        self.iou_counts.zero_()
-        L.check(lib.nunet_iou_counts(L.ptr(self.logits, (self.heads - 1) * plane), L.ptr(self.t), self.n * self.per,
-                                     L.ptr(self.iou_counts), st), "iou_counts")
-        for k in range(self.heads):
-            L.check(lib.nunet_bce_dice_bwd(L.ptr(self.logits, k * plane), L.ptr(self.t), self.n, self.per,
-                                           L.ptr(self.loss_ws, k * self.ws_stride * 4), L.ptr(self.gscale),
-                                           L.ptr(self.dlogits, k * plane), st), "bce_dice_bwd")
+        L.check(lib.nunet_loss_step(L.ptr(self.logits), L.ptr(self.t), self.n, self.per, self.heads, L.ptr(self.loss_ws),
+                                    L.ptr(self.dlogits), L.ptr(self.loss_out), L.ptr(self.meters), st), "loss_step")
         L.check(lib.nunet_plan_backward(pl.handle, L.ptr(eng.flat_params), L.ptr(self.dlogits), L.ptr(pl.arena),
                                         L.ptr(eng.flat_grads), 0, st), "plan_backward")
-        # meters (device side): loss = mean over heads; iou = (I+eps)/(U+eps) of this step
-        self.loss_sum += self.loss_heads.mean()
-        c = self.iou_counts.double()
-        self.iou_sum += (c[0] + 1e-5) / (c[1] + 1e-5)
         pl.trained_forward = True
 
     def _opt(self):
@@ -101,7 +83,7 @@ class TrainStep:
         eng = self.eng
         self.x.copy_(inp)
         self.t.copy_(target)
-        snap = [t.clone() for t in (eng.flat_params, eng.bnbuf, eng.nbt, self.mom, self.loss_sum, self.iou_sum)]
+        snap = [t.clone() for t in (eng.flat_params, eng.bnbuf, eng.nbt, self.mom, self.meters)]
         steps0 = self.steps
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -123,7 +105,7 @@ class TrainStep:
                 self._opt()
         torch.cuda.synchronize()
         with torch.no_grad():
-            for dst, src in zip((eng.flat_params, eng.bnbuf, eng.nbt, self.mom, self.loss_sum, self.iou_sum), snap):
+            for dst, src in zip((eng.flat_params, eng.bnbuf, eng.nbt, self.mom, self.meters), snap):
                 dst.copy_(src)
         self.steps = steps0
 
@@ -148,15 +130,15 @@ class TrainStep:
         self.lr.fill_(lr)
 
     def reset_meters(self):
-        self.loss_sum.zero_()
-        self.iou_sum.zero_()
+        self.meters.zero_()
         self.steps = 0
 
     def epoch_stats(self):
         """(mean loss, mean IoU) over the steps since reset_meters(); one host sync.
         Equal-sized batches make this the sample-weighted AverageMeter of utils.py:29-33."""
         k = max(self.steps, 1)
-        return float(self.loss_sum.item()) / k, float(self.iou_sum.item()) / k
+        m = self.meters.tolist()
+        return m[0] / k, m[1] / k
 
 
 def cosine_lr(base_lr, min_lr, epoch, t_max):
