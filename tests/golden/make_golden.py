@@ -193,9 +193,55 @@ def run_small_ops():
     print("small_ops ok", int(out["count_params"]))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     torch.set_num_threads(8)
     for name, cfg in CASES.items():
         run_case(name, cfg)
     run_trajectory()
     run_small_ops()
+
+
+def run_training_log(epochs=6, train_size=256, val_size=64, bs=16, hw=96, lr=1e-2):
+    """'val IoU vs ref' in its offline-feasible form: the REFERENCE model/loss/metric
+    trained here with torch.optim.SGD + CosineAnnealingLR (trains.py:229-239) on the seeded synthetic
+    blob set, the same shuffle stream as train.py. Commits the per-epoch log as a fixture."""
+    torch.manual_seed(41)
+    model = ref_archs.NestedUNet(1, 3, False)
+    crit = ref_losses.BCEDiceLoss()
+    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, nesterov=False, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=epochs, eta_min=1e-5)
+    img, msk = synth.synth_batch(train_size, hw, hw, 3, 1, seed=1000)
+    vimg, vmsk = synth.synth_batch(val_size, hw, hw, 3, 1, seed=2000)
+    x, t = torch.from_numpy(img), torch.from_numpy(msk)
+    vx, vt = torch.from_numpy(vimg), torch.from_numpy(vmsk)
+    g = torch.Generator().manual_seed(41)
+    rows = []
+    for ep in range(epochs):
+        perm = torch.randperm(train_size, generator=g)
+        ml, mi = ref_utils.AverageMeter(), ref_utils.AverageMeter()
+        model.train()
+        for k in range(train_size // bs):
+            idx = perm[k * bs:(k + 1) * bs]
+            o = model(x[idx])
+            loss = crit(o, t[idx])
+            iou = ref_metrics.iou_score(o, t[idx])
+            opt.zero_grad(); loss.backward(); opt.step()
+            ml.update(loss.item(), bs); mi.update(iou, bs)
+        lr_now = opt.param_groups[0]["lr"]
+        sched.step()
+        model.eval()
+        vl, vi = ref_utils.AverageMeter(), ref_utils.AverageMeter()
+        with torch.no_grad():
+            for k in range(0, val_size, bs):
+                o = model(vx[k:k + bs])
+                vl.update(crit(o, vt[k:k + bs]).item(), o.size(0)); vi.update(ref_metrics.iou_score(o, vt[k:k + bs]), o.size(0))
+        rows.append((ep, lr_now, ml.avg, mi.avg, vl.avg, vi.avg))
+        print("train-log epoch", rows[-1], flush=True)
+    np.savez_compressed(os.path.join(HERE, "train_log_blobs.npz"), log=np.array(rows, dtype=np.float64),
+                        columns=np.array(["epoch", "lr", "loss", "iou", "val_loss", "val_iou"]),
+                        config=np.array([epochs, train_size, val_size, bs, hw, lr]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "trainlog":
+    torch.set_num_threads(8)
+    run_training_log()

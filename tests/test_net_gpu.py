@@ -296,3 +296,50 @@ def test_fused_train_step_graph_matches_eager_and_oracle(synth):
         w = m.conv0_4.conv2.weight.detach().cpu()
         rw = net.params["conv0_4.conv2.weight"].detach()
         assert float((w - rw).abs().max()) < 2e-5
+
+
+def test_training_log_follows_reference(synth):
+    """'val IoU vs ref' in its offline form: the reference model/loss/metric trained on the
+    seeded blob set (tests/golden/make_golden.py trainlog: SGD 1e-2, momentum 0.9, wd 1e-4, cosine, 6 epochs
+    of 256 images, bs 16, 96x96) vs the same loop on the HIP path (same init seed, same shuffle stream)."""
+    from nunet_amd.trainer import TrainStep, cosine_lr
+    from nunet_amd.metrics import iou_counts, iou_from_counts
+    g = load_golden("train_log_blobs")
+    ref = g["log"]
+    epochs, train_size, val_size, bs, hw, lr = (int(v) if k < 5 else float(v) for k, v in enumerate(g["config"]))
+    torch.manual_seed(41)
+    m = nunet_amd.archs.NestedUNet(1, 3, False).to(DEV).train()
+    img, msk = synth.synth_batch(train_size, hw, hw, 3, 1, seed=1000)
+    vimg, vmsk = synth.synth_batch(val_size, hw, hw, 3, 1, seed=2000)
+    x, t = torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV)
+    vx, vt = torch.from_numpy(vimg).to(DEV), torch.from_numpy(vmsk).to(DEV)
+    ts = TrainStep(m, (bs, 3, hw, hw), lr=lr, momentum=0.9, weight_decay=1e-4)
+    ts.capture(x[:bs], t[:bs])
+    crit = nunet_amd.losses.BCEDiceLoss()
+    gen = torch.Generator().manual_seed(41)
+    rows = []
+    for ep in range(epochs):
+        perm = torch.randperm(train_size, generator=gen).to(DEV)
+        ts.set_lr(cosine_lr(lr, 1e-5, ep, epochs))
+        ts.reset_meters()
+        m.train()
+        for k in range(train_size // bs):
+            idx = perm[k * bs:(k + 1) * bs]
+            ts.step(x[idx], t[idx])
+        tl, ti = ts.epoch_stats()
+        m.eval()
+        vl = vi = 0.0
+        with torch.no_grad():
+            for k in range(0, val_size, bs):
+                o = m(vx[k:k + bs].contiguous())
+                vl += float(crit(o, vt[k:k + bs].contiguous())) * bs
+                vi += iou_from_counts(iou_counts(o.contiguous(), vt[k:k + bs].contiguous())) * bs
+        rows.append((tl, ti, vl / val_size, vi / val_size))
+        print("epoch", ep, "hip", rows[-1], "ref", tuple(ref[ep][2:]))
+    rows = np.array(rows)
+    # the loop is chaotic at the 1e-2 level after ~100 steps; bands, not equality
+    assert abs(ref[0][1] - lr) < 1e-12
+    assert np.all(np.abs(rows[:, 0] - ref[:, 2]) < 0.04), (rows[:, 0], ref[:, 2])          # train loss per epoch
+    assert np.all(np.abs(rows[:, 1] - ref[:, 3]) < 0.08), (rows[:, 1], ref[:, 3])          # train IoU per epoch
+    assert rows[-1, 0] < rows[0, 0] - 0.2                                                  # it learns
+    assert np.all(np.abs(rows[:, 2] - ref[:, 4]) < 0.15), (rows[:, 2], ref[:, 4])          # val loss (eval-mode BN: noisier)

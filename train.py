@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Training driver for the MI355X UNet++ path — the counterpart of reference trains.py
+(flags :31-103, loop :106-188, main :191-356) on the seeded synthetic blob dataset
+(pytorch_nested-unet_amd/synth.py; DSB2018 is not available offline).
+
+Same artefacts as the reference: models/<name>/config.yml (trains.py:206-207),
+models/<name>/log.csv with columns epoch, lr, loss, iou, val_loss, val_iou (:304-311,331-339),
+models/<name>/model.pth = state_dict at the best val IoU (:344-349), early stopping (:351-354).
+The `lr` column logs the scheduler's current lr (the reference logs the constant initial lr, :332).
+"""
+import argparse
+import os
+import time
+from collections import OrderedDict
+
+import torch
+import yaml
+
+import nunet_amd
+from nunet_amd import archs, losses
+from nunet_amd.metrics import iou_counts, iou_from_counts
+from nunet_amd.trainer import TrainStep, cosine_lr
+from nunet_amd.utils import AverageMeter, str2bool
+
+ARCH_NAMES = archs.__all__
+LOSS_NAMES = losses.__all__
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--name', default=None, help='model name: (default: arch+timestamp)')
+    p.add_argument('--epochs', default=100, type=int)
+    p.add_argument('-b', '--batch_size', default=16, type=int)
+    p.add_argument('--arch', '-a', default='NestedUNet', choices=ARCH_NAMES)
+    p.add_argument('--deep_supervision', default=False, type=str2bool)
+    p.add_argument('--input_channels', default=3, type=int)
+    p.add_argument('--num_classes', default=1, type=int)
+    p.add_argument('--input_w', default=96, type=int)
+    p.add_argument('--input_h', default=96, type=int)
+    p.add_argument('--loss', default='BCEDiceLoss', choices=LOSS_NAMES)
+    p.add_argument('--dataset', default='synthetic_blobs')
+    p.add_argument('--optimizer', default='SGD', choices=['Adam', 'SGD'])
+    p.add_argument('--lr', '--learning_rate', default=1e-3, type=float)
+    p.add_argument('--momentum', default=0.9, type=float)
+    p.add_argument('--weight_decay', default=1e-4, type=float)
+    p.add_argument('--nesterov', default=False, type=str2bool)
+    p.add_argument('--scheduler', default='CosineAnnealingLR', choices=['CosineAnnealingLR', 'ConstantLR'])
+    p.add_argument('--min_lr', default=1e-5, type=float)
+    p.add_argument('--early_stopping', default=-1, type=int)
+    p.add_argument('--num_workers', default=0, type=int, help='accepted for compatibility; data is generated in-process')
+    # additions
+    p.add_argument('--dtype', default='bf16', choices=['fp32', 'bf16', 'fp16'])
+    p.add_argument('--train_size', default=512, type=int)
+    p.add_argument('--val_size', default=128, type=int)
+    p.add_argument('--seed', default=41, type=int)
+    return p.parse_args()
+
+
+def make_split(n, h, w, cin, ncls, seed):
+    img, msk = nunet_amd.synth.synth_batch(n, h, w, cin, ncls, seed=seed)
+    return torch.from_numpy(img), torch.from_numpy(msk)
+
+
+def validate(config, data, model, criterion):
+    """reference trains.py:150-188."""
+    avg = {'loss': AverageMeter(), 'iou': AverageMeter()}
+    model.eval()
+    x, t = data
+    bs = config['batch_size']
+    with torch.no_grad():
+        for k in range(0, x.size(0), bs):
+            xb, tb = x[k:k + bs].contiguous(), t[k:k + bs].contiguous()
+            out = model(xb)
+            if config['deep_supervision']:
+                loss = sum(criterion(o, tb) for o in out) / len(out)
+                last = out[-1]
+            else:
+                loss = criterion(out, tb)
+                last = out
+            avg['loss'].update(loss.item(), xb.size(0))
+            avg['iou'].update(iou_from_counts(iou_counts(last.contiguous(), tb)), xb.size(0))
+    return OrderedDict([('loss', avg['loss'].avg), ('iou', avg['iou'].avg)])
+
+
+def main():
+    config = vars(parse_args())
+    if config['name'] is None:
+        config['name'] = '%s_%s_%s' % (config['dataset'], config['arch'], 'wDS' if config['deep_supervision'] else 'woDS')
+    os.makedirs('models/%s' % config['name'], exist_ok=True)
+    print('-' * 20)
+    for k, v in config.items():
+        print('%s: %s' % (k, v))
+    print('-' * 20)
+    with open('models/%s/config.yml' % config['name'], 'w') as f:
+        yaml.dump(config, f)
+
+    criterion = losses.__dict__[config['loss']]().cuda()
+    torch.manual_seed(config['seed'])
+    model = archs.__dict__[config['arch']](config['num_classes'], config['input_channels'], config['deep_supervision'],
+                                           dtype=config['dtype'])
+    model = model.cuda()
+    h, w, bs = config['input_h'], config['input_w'], config['batch_size']
+    # the synthetic splits live in HBM (a few MB); batches are gathered on the device
+    train = tuple(v.cuda() for v in make_split(config['train_size'], h, w, config['input_channels'], config['num_classes'], 1000))
+    val = tuple(v.cuda() for v in make_split(config['val_size'], h, w, config['input_channels'], config['num_classes'], 2000))
+    steps = config['train_size'] // bs          # drop_last=True (trains.py:296)
+
+    fused = config['optimizer'] == 'SGD'
+    if fused:
+        model.train()
+        ts = TrainStep(model, (bs, config['input_channels'], h, w), lr=config['lr'], momentum=config['momentum'],
+                       weight_decay=config['weight_decay'], nesterov=config['nesterov'])
+        ts.capture(train[0][:bs], train[1][:bs])
+    else:
+        params = filter(lambda p: p.requires_grad, model.parameters())
+        optimizer = torch.optim.Adam(params, lr=config['lr'], weight_decay=config['weight_decay'])
+
+    log = OrderedDict([(k, []) for k in ('epoch', 'lr', 'loss', 'iou', 'val_loss', 'val_iou', 'images_per_sec')])
+    best_iou, trigger = 0, 0
+    g = torch.Generator().manual_seed(config['seed'])   # host-side permutation: identical for any device
+    for epoch in range(config['epochs']):
+        lr = config['lr'] if config['scheduler'] == 'ConstantLR' else cosine_lr(config['lr'], config['min_lr'], epoch, config['epochs'])
+        perm = torch.randperm(config['train_size'], generator=g).cuda()
+        model.train()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if fused:
+            ts.set_lr(lr)
+            ts.reset_meters()
+            for k in range(steps):
+                idx = perm[k * bs:(k + 1) * bs]
+                ts.step(train[0][idx], train[1][idx])
+            tl, ti = ts.epoch_stats()
+        else:
+            for gpar in optimizer.param_groups:
+                gpar['lr'] = lr
+            ml, mi = AverageMeter(), AverageMeter()
+            for k in range(steps):                                       # reference trains.py:113-135
+                idx = perm[k * bs:(k + 1) * bs]
+                xb, tb = train[0][idx], train[1][idx]
+                out = model(xb)
+                if config['deep_supervision']:
+                    loss = sum(criterion(o, tb) for o in out) / len(out)
+                    last = out[-1]
+                else:
+                    loss = criterion(out, tb)
+                    last = out
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                ml.update(loss.item(), bs)
+                mi.update(iou_from_counts(iou_counts(last.detach().contiguous(), tb)), bs)
+            tl, ti = ml.avg, mi.avg
+        torch.cuda.synchronize()
+        ips = steps * bs / (time.perf_counter() - t0)
+        val_log = validate(config, val, model, criterion)
+        print('Epoch [%d/%d] loss %.4f - iou %.4f - val_loss %.4f - val_iou %.4f - %.0f img/s'
+              % (epoch, config['epochs'], tl, ti, val_log['loss'], val_log['iou'], ips))
+        for k, v in zip(log, (epoch, lr, tl, ti, val_log['loss'], val_log['iou'], ips)):
+            log[k].append(v)
+        with open('models/%s/log.csv' % config['name'], 'w') as f:
+            f.write(','.join(log.keys()) + '\n')
+            for r in range(len(log['epoch'])):
+                f.write(','.join(str(log[k][r]) for k in log) + '\n')
+        trigger += 1
+        if val_log['iou'] > best_iou:
+            torch.save(model.state_dict(), 'models/%s/model.pth' % config['name'])
+            best_iou = val_log['iou']
+            print("=> saved best model")
+            trigger = 0
+        if 0 <= config['early_stopping'] <= trigger:
+            print("=> early stopping")
+            break
+
+
+if __name__ == '__main__':
+    main()
