@@ -63,6 +63,8 @@ typedef struct {
   uint32_t acc0_mask;               /* bit k: dst0 slot k accumulates (+=) */
   int32_t acc1;                     /* dst1 accumulates */
   float* stats;                     /* [2][Cout] fp32: += sum(y-b), sum((y-b)^2) or NULL */
+  float* splitk_ws;                 /* optional fp32 scratch: lets grid-starved layers split the contraction */
+  int64_t splitk_ws_floats;         /* over workgroups (S slabs of N*H*W*Cout floats). NULL: never split */
 } nunet_conv_desc;
 
 /* y = conv(cat(src0,src1)) + bias. Also used as dgrad with the flipped,

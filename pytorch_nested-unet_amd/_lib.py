@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("dst0", _vp), ("D0", _i32), ("Q0", _i32),
                 ("dst1", _vp), ("D1", _i32), ("Q1", _i32),
                 ("acc_slot_w", _i32), ("acc0_mask", _u32), ("acc1", _i32),
-                ("stats", _vp)]
+                ("stats", _vp), ("splitk_ws", _vp), ("splitk_ws_floats", _i64)]
 
 
 class WgradDesc(C.Structure):

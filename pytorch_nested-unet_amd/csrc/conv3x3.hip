@@ -68,6 +68,9 @@ struct ConvP {
   float* stats;
   int N, H, W, Cin, Cout;
   int NI, TH, TW, tilesX, tilesY, tilesG, nCoT, nItems;
+  int S, nch0, nch;      // K-split: slices, channel chunks of source 0 / total (SK kernels only)
+  float* slabs;          // [S][pixels][Cout] fp32 partial sums
+  long long slab_stride; // pixels * Cout
 };
 
 template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
@@ -93,7 +96,7 @@ template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
 // The global loads of the NEXT (item, channel chunk) are issued into registers before the
 // current chunk's MFMA sweep, so HBM latency hides under compute and under the previous
 // tile's epilogue, and co-resident workgroups de-synchronise their load/compute/store phases.
-template <typename T, int WM, int WN, int SM, int SN>
+template <typename T, int WM, int WN, int SM, int SN, bool SK>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
   typedef Mma<T> M;
@@ -150,9 +153,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
     hcode[k] = hp < C::HPMAX ? s_hxy[hp] : -1;
   }
 
-  struct Item { int co0, n0, y0, x0; };
+  struct Item { int co0, n0, y0, x0, ks; };
   auto decode = [&](int item) {
     Item it;
+    it.ks = 0;
+    if constexpr (SK) { it.ks = item % p.S; item /= p.S; }
     it.co0 = (item % p.nCoT) * BN; item /= p.nCoT;
     it.x0 = (item % p.tilesX) * p.TW; item /= p.tilesX;
     it.y0 = (item % p.tilesY) * p.TH;
@@ -217,12 +222,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
+  // K-split kernels walk channel CHUNKS [c_lo, c_hi) of their slice; plain kernels walk channels
+  auto chunk_kb = [&](int c) { return c < p.nch0 ? c * C::KC : p.C0 + (c - p.nch0) * C::KC; };
+  auto chunk_kc = [&](int c) { return min(C::KC, (c < p.nch0 ? p.C0 : p.Cin) - chunk_kb(c)); };
   int item = blockIdx.x;
   if (item >= p.nItems) return;
   Item cur = decode(item);
   set_hgp(cur);
-  int kb = 0;
-  int kc = min(C::KC, (kb < p.C0 ? p.C0 : p.Cin) - kb);
+  int cc = 0, c_hi = 0;
+  int kb = 0, kc = 0;
+  if constexpr (SK) { cc = cur.ks * p.nch / p.S; c_hi = (cur.ks + 1) * p.nch / p.S; kb = chunk_kb(cc); kc = chunk_kc(cc); }
+  else { kc = min(C::KC, (kb < p.C0 ? p.C0 : p.Cin) - kb); }
   load_regs(cur, kb, kc);
   bool first_chunk = true;
   constexpr int NSTEP = 9 * KS;
@@ -243,18 +253,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
     }
     __syncthreads();
     // prefetch the next (item, chunk) into registers
-    int nkb = kb + kc, nkc = 0, nitem = item;
+    int nkb = kb + kc, nkc = 0, nitem = item, ncc = cc + 1, nc_hi = c_hi;
     Item nxt = cur;
     bool have_next = true;
-    const bool last_chunk = nkb >= p.Cin;
+    bool last_chunk;
+    if constexpr (SK) last_chunk = ncc >= c_hi; else last_chunk = nkb >= p.Cin;
     if (last_chunk) {
       nkb = 0;
       nitem = item + gridDim.x;
-      if (nitem < p.nItems) { nxt = decode(nitem); set_hgp(nxt); }
-      else have_next = false;
+      if (nitem < p.nItems) {
+        nxt = decode(nitem); set_hgp(nxt);
+        if constexpr (SK) { ncc = nxt.ks * p.nch / p.S; nc_hi = (nxt.ks + 1) * p.nch / p.S; }
+      } else have_next = false;
     }
     if (have_next) {
-      nkc = min(C::KC, (nkb < p.C0 ? p.C0 : p.Cin) - nkb);
+      if constexpr (SK) { nkb = chunk_kb(ncc); nkc = chunk_kc(ncc); }
+      else nkc = min(C::KC, (nkb < p.C0 ? p.C0 : p.Cin) - nkb);
       load_regs(nxt, nkb, nkc);
     }
     // fully unrolled tap x k-step sweep; fragments of step s+1 are read while step s multiplies
@@ -281,7 +295,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       }
     }
     first_chunk = false;
-    if (last_chunk) {
+    if (SK && last_chunk) {
+      // ---- K-split epilogue: this slice's fp32 partial tile goes to its slab (plain stores,
+      // 128-byte runs per half-wave); splitk_finalize_kernel sums the slabs deterministically
+      float* slab = p.slabs + (size_t)cur.ks * p.slab_stride;
+#pragma unroll
+      for (int b = 0; b < SN; ++b) {
+        const int co = cur.co0 + (wn * SN + b) * 32 + r;
+#pragma unroll
+        for (int a = 0; a < SM; ++a) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int gp = s_gpix[(wm * SM + a) * 32 + acc_row(i, h)];
+            if (gp >= 0) slab[(size_t)gp * p.Cout + co] = acc[a][b][i];
+            acc[a][b][i] = 0.f;
+          }
+        }
+      }
+      if (!have_next) break;
+      cur = nxt; item = nitem; first_chunk = true;
+    } else if (last_chunk) {
       // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
       __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
       T* const s_out = s_buf;
@@ -350,9 +383,66 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       if (!have_next) break;
       cur = nxt; item = nitem; first_chunk = true;
     }
-    kb = nkb; kc = nkc;
+    kb = nkb; kc = nkc; cc = ncc; c_hi = nc_hi;
   }
 }
+
+// Finishes a K-split convolution: sum of the S fp32 slabs (fixed order: deterministic) -> (+bias)
+// -> T, routed to the two destinations with the per-slot accumulate mask, BatchNorm partial sums.
+struct SplitFinP {
+  const float* slabs; long long slab_stride; int S; const float* bias;
+  void* dst0; void* dst1; int D0, D1, Q0, Q1; int slot_w; unsigned acc0_mask; int acc1;
+  float* stats; long long npix; int Cout;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
+  constexpr int EPV = Tr<T>::EPV;
+  __shared__ float s_st[2 * 1024];
+  const int G = p.Cout / EPV;
+  if (p.stats) for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x) s_st[c] = 0.f;
+  __syncthreads();
+  const long long total = p.npix * G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    const long long pix = i / G;
+    const int co = cg * EPV;
+    float x[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) x[e] = 0.f;
+    for (int k = 0; k < p.S; ++k) {
+      const f32x4* w = reinterpret_cast<const f32x4*>(p.slabs + (size_t)k * p.slab_stride + pix * p.Cout + co);
+#pragma unroll
+      for (int v4 = 0; v4 < EPV / 4; ++v4) {
+        const f32x4 q4 = w[v4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[v4 * 4 + e] += q4[e];
+      }
+    }
+    T* q; bool accum;
+    if (co < p.D0) { q = (T*)p.dst0 + pix * p.Q0 + co; accum = (p.acc0_mask >> (p.slot_w > 0 ? co / p.slot_w : 0)) & 1u; }
+    else { q = (T*)p.dst1 + pix * p.Q1 + (co - p.D0); accum = p.acc1 != 0; }
+    const Vec16<T> o = accum ? ld16(q) : zero16<T>();
+    Vec16<T> v;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float b = p.bias ? p.bias[co + e] : 0.f;
+      float y = x[e] + b;
+      if (accum) y += o.get(e);
+      v.set(e, y);
+      if (p.stats) {
+        const float d = v.get(e) - b;
+        atomicAdd(&s_st[co + e], d);
+        atomicAdd(&s_st[p.Cout + co + e], d * d);
+      }
+    }
+    st16(q, v);
+  }
+  if (p.stats) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x) atomicAdd(&p.stats[c], s_st[c]);
+  }
+}
+
 
 // tile-geometry chooser shared by fwd and wgrad
 struct TileGeom { int NI, TH, TW, tilesX, tilesY, tilesG; };
@@ -391,7 +481,20 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG;
   p.nCoT = p.Cout / C::BN;
-  const long items = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
+  long items = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
+  // K-split for the grid-starved deep levels: slices of the channel-chunk loop become extra items, each
+  // writes an fp32 partial slab; splitk_finalize_kernel sums them (fixed order, deterministic)
+  p.S = 1; p.slabs = nullptr; p.slab_stride = 0;
+  p.nch0 = ceil_div(p.C0, C::KC);
+  p.nch = p.nch0 + (p.C1 > 0 ? ceil_div(p.C1, C::KC) : 0);
+  if (d->splitk_ws && items <= 100 && p.nch >= 8 && p.Cout <= 1024) {
+    int S = (int)((320 + items - 1) / items);
+    if (S > p.nch / 2) S = p.nch / 2;
+    const long long need = (long long)S * d->N * d->H * d->W * p.Cout;
+    if (S > 1 && need <= d->splitk_ws_floats) {
+      p.S = S; p.slabs = d->splitk_ws; p.slab_stride = (long long)d->N * d->H * d->W * p.Cout; items *= S;
+    }
+  }
   p.nItems = (int)items;
   // persistent grid: resident workgroups only, item counts balanced across them
   const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN;
@@ -403,16 +506,37 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   const long grid = (items + rounds - 1) / rounds;
   const double px = (double)d->N * d->H * d->W;
   const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
-  ProfScope ps(C::BN == 32 ? PC_CONV_M256N32 : PC_CONV_M128N64, 2.0 * 9 * acin * p.Cout * px,
+  ProfScope ps(C::BN == 32 ? PC_CONV_M256N32 : PC_CONV_M128N64,  /* BN 64 configs share a class */ 2.0 * 9 * acin * p.Cout * px,
                (px * (acin + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
-  hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  if (p.S > 1) {
+    hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+    SplitFinP f;
+    f.slabs = p.slabs; f.slab_stride = p.slab_stride; f.S = p.S; f.bias = p.bias;
+    f.dst0 = p.dst0; f.dst1 = p.dst1; f.D0 = p.D0; f.D1 = p.D1; f.Q0 = p.Q0; f.Q1 = p.Q1;
+    f.slot_w = p.slot_w; f.acc0_mask = p.acc0_mask; f.acc1 = p.acc1; f.stats = p.stats;
+    f.npix = (long long)d->N * d->H * d->W; f.Cout = p.Cout;
+    long long fg = (f.npix * (p.Cout / C::EPV) + 255) / 256;
+    if (fg > 1024) fg = 1024;
+    hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3((unsigned)fg), dim3(256), 0, st, f);
+    return nunet_check_launch("conv3x3 (K-split)");
+  }
+  hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   return nunet_check_launch("conv3x3");
 }
 
 template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream_t st) {
   const int cout = d->D0 + d->D1;
-  if (cout % 64 == 0) return launch_conv_cfg<T, 2, 2, 2, 1>(d, st);  // BM 128, BN 64
-  return launch_conv_cfg<T, 4, 1, 2, 1>(d, st);                      // BM 256, BN 32
+  static int big = -1;   // measured: the 256x64 tile drops to 1 wave/SIMD (296 registers) and loses; off by default
+  if (big < 0) { const char* e = getenv("NUNET_CONV_BIG"); big = e ? atoi(e) : 0; }
+  const long px = (long)d->N * d->H * d->W;
+  if (cout % 64 == 0) {
+    // deep pyramid levels are weight-streaming bound: every M-tile re-reads the layer's whole weight
+    // slab, so few pixels -> the largest tile (256 px x 64 co, 64x64 per wave: 1.0 LDS reads per MFMA),
+    // parallelism restored by the K-split
+    if (big && px <= big * 10000L && d->splitk_ws) return launch_conv_cfg<T, 4, 1, 2, 2>(d, st);   // BM 256, BN 64
+    return launch_conv_cfg<T, 2, 2, 2, 1>(d, st);                                       // BM 128, BN 64
+  }
+  return launch_conv_cfg<T, 4, 1, 2, 1>(d, st);                                         // BM 256, BN 32
 }
 
 extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {

@@ -385,3 +385,36 @@ def test_argument_errors_are_loud():
     m = nunet_amd.archs.NestedUNet(1).to(DEV)
     with pytest.raises(L.NunetError):
         m(torch.zeros(1, 3, 40, 40, device=DEV))                          # not a multiple of 16
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+def test_conv3x3_splitk_slabs(dt):
+    """Grid-starved long-K shape: the K-split path (fp32 slabs + deterministic finalize) gives the same
+    outputs / BN sums / accumulate semantics as the single-pass kernel, bit-identically run to run."""
+    n, h, w, c0, c1, cout = 2, 12, 12, 256, 256, 128
+    g = torch.Generator().manual_seed(21)
+    cin = c0 + c1
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    prev = torch.randn(n, cout, h, w, generator=g)
+    s0, s1 = nhwc(x[:, :c0], dt), nhwc(x[:, c0:], dt)
+    wf, _ = pack(wt, dt)
+    ws = torch.full((8 * n * h * w * cout + 4,), 7.0, dtype=torch.float32, device=DEV)   # garbage: slabs are fully overwritten
+    outs = []
+    for accum in (0, 1, 0):
+        y = nhwc(prev, dt)
+        stats = torch.zeros(2 * cout, dtype=torch.float32, device=DEV)
+        d = conv_desc(dt, n, h, w, s0, c0, c0, wf, y, cout, cout, src1=s1, c1=c1, p1=c1, stats=stats,
+                      slot_w=cout, mask=accum)
+        d.splitk_ws = L.ptr(ws).value
+        d.splitk_ws_floats = 8 * n * h * w * cout
+        L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "conv splitk")
+        ref = F.conv2d(q(x, dt).double(), q(wt, dt).double(), None, padding=1)
+        exp = ref + (q(prev, dt).double() if accum else 0)
+        assert rel_err(to_nchw(y, cout), exp) < TOL[dt]
+        if not accum:
+            got = to_nchw(y, cout).double()
+            m = n * h * w
+            np.testing.assert_allclose(stats[:cout].cpu().numpy() / m, got.sum((0, 2, 3)).numpy() / m, atol=1e-4)
+            outs.append(y.clone())
+    assert torch.equal(outs[0], outs[1])
