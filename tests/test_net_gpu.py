@@ -122,8 +122,8 @@ def test_fp32_matches_reference_goldens(name, synth):
         err_mine = float((mine - g64).norm()) / (nrm + 1e-30)
         worst = max(worst, err_mine)
         assert err_mine < max(3 * err_ref, 2e-3), (nm, err_mine, err_ref)
-        # the golden (reference fp32) summary agrees too
-        assert abs(float(mine.norm()) - g["grad_l2"][k]) < 0.03 * g["grad_l2"][k] + 1e-7, nm
+        # the golden (reference fp32) summary agrees too, within the reference's own conditioning
+        assert abs(float(mine.norm()) - g["grad_l2"][k]) < max(0.03, 3 * err_ref) * g["grad_l2"][k] + 1e-7, nm
     print(name, "worst grad rel err vs fp64 oracle:", worst)
 
 
