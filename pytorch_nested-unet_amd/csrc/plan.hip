@@ -175,7 +175,7 @@ struct nunet_plan {
   size_t off_wpack; long long wpack_elems;
   size_t off_img;
   size_t X[5], GX[5];
-  size_t off_dy[5][2], off_da1[5], off_gup[5], off_gpin[5];
+  size_t off_dy[16][2], off_da1[16], off_gup[16], off_gpin[16];   // per-BLOCK backward scratch (dY ping-pong), so blocks of one level can run on different lanes
   size_t off_sk[5]; long long sk_floats[5];   // per-level fp32 K-split slabs (levels 3, 4)   // per-level backward scratch (dY ping-pong)
   struct PlanRt* rt;
   size_t total;
@@ -288,12 +288,13 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     if (n.up_slot >= 0) n.up = bump(cur, (size_t)P->px[n.i] * NBF[n.i + 1] * P->es);
     if (n.in_prefix == 0 && n.i > 0) n.pin = bump(cur, (size_t)P->px[n.i] * NBF[n.i - 1] * P->es);
   }
-  for (int i = 0; i < 5; ++i) {
+  for (size_t k = 0; k < P->exec.size(); ++k) {
+    const int i = P->exec[k].i;
     const size_t plane = (size_t)P->px[i] * NBF[i] * P->es;
-    P->off_dy[i][0] = bump(cur, plane); P->off_dy[i][1] = bump(cur, plane);
-    P->off_da1[i] = bump(cur, plane);
-    P->off_gup[i] = bump(cur, i < 4 ? (size_t)P->px[i] * NBF[i + 1] * P->es : 256);
-    P->off_gpin[i] = bump(cur, i > 0 ? (size_t)P->px[i] * NBF[i - 1] * P->es : 256);
+    P->off_dy[k][0] = bump(cur, plane); P->off_dy[k][1] = bump(cur, plane);
+    P->off_da1[k] = bump(cur, plane);
+    P->off_gup[k] = bump(cur, i < 4 ? (size_t)P->px[i] * NBF[i + 1] * P->es : 256);
+    P->off_gpin[k] = bump(cur, i > 0 ? (size_t)P->px[i] * NBF[i - 1] * P->es : 256);
   }
   // K-split slabs for the grid-starved levels 3 and 4 (up to 8 slices of the widest output at the
   // level); deterministic (fixed summation order). Measured +1.2 % on the bench; NUNET_SPLITK=0 disables.
@@ -396,8 +397,8 @@ static inline char* AB(void* arena, size_t off) { return (char*)arena + off; }
 // per-buffer tracker (last-writer event, last-reader event per lane). Captured by the
 // caller, the lanes become parallel branches of ONE hipGraph.
 // ---------------------------------------------------------------------------
-#define NRES 320
-enum { R_X = 0, R_GX = 25, R_BLK = 50, R_LVL = 180, R_IMG = 230, R_LOGITS = 231, R_DLOGITS = 232, R_WP = 233, R_GS = 238, R_GSW = 240, R_GSV = 280 };
+#define NRES 480
+enum { R_X = 0, R_GX = 25, R_BLK = 50, R_LVL = 330, R_IMG = 230, R_LOGITS = 231, R_DLOGITS = 232, R_WP = 233, R_GS = 238, R_SK = 470, R_GSW = 240, R_GSV = 280 };
 enum { B_Y1 = 0, B_A1, B_Y2, B_UP, B_PIN, B_ST1, B_ST2, B_STRIDE = 8 };
 enum { L_DY0 = 0, L_DY1, L_DA1, L_GUP, L_GPIN, L_STRIDE = 8 };
 
@@ -538,6 +539,23 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass) {
   }
 }
 
+// Lane of a block. Crossing HW queues costs 5-10 us of dispatch latency per dependency edge, so the
+// assignment decides how many edges of the critical chain (B00>B10>B20>B30>B40>B31>B22>B13>B04 and its
+// mirror in backward) cross lanes. NUNET_LANE_MODE: 0 = pyramid level, 1 = anti-diagonal,
+// 2 = critical chain on lane 0 and the side blocks on lanes 1-3 by anti-diagonal.
+static int lane_of(const nunet_plan* P, const Node& n) {
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("NUNET_LANE_MODE"); mode = e ? atoi(e) : 2; }   // measured best: 2
+  if (P->cfg.unet || mode == 0) return n.i;
+  if (mode == 1) return (n.i + n.j) % 5;
+  if (n.j == 0 || n.i + n.j == 4) return 0;
+  if (mode == 2) return n.i + n.j;           // side blocks: diagonals 1..3 -> lanes 1..3
+  if (mode == 3) return 1 + n.i;             // side blocks by level 0..2 -> lanes 1..3
+  if (mode == 4) return n.j;                 // side blocks by column 1..3 -> lanes 1..3
+  if (mode == 5) return 1 + (n.i + n.j) % 2; // two side lanes
+  return 1;                                  // mode 6: one side lane
+}
+
 static int blk_index(const nunet_plan* P, int i, int in_prefix_zero_only) {
   for (size_t q = 0; q < P->exec.size(); ++q)
     if (P->exec[q].i == i && (!in_prefix_zero_only || P->exec[q].in_prefix == 0)) return (int)q;
@@ -589,7 +607,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   for (size_t k = 0; k < P->exec.size() && rc == NUNET_OK; ++k) {
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
-    const int lane = i, rb = R_BLK + (int)k * B_STRIDE;
+    const int lane = lane_of(P, n), rb = R_BLK + (int)k * B_STRIDE;
     if (n.up_slot >= 0) {
       hipStream_t ls = S.begin(lane, {R_X + (i + 1) * 5 + n.up_slot}, {rb + B_UP});
       rc = nunet_upsample2x_fwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1],
@@ -605,15 +623,15 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       hipStream_t ls;
       if (cv == 1) {
         d.src0 = AB(arena, n.a1); d.C0 = f; d.P0 = f;
-        ls = S.begin(lane, {rb + B_A1, R_WP + i}, {rb + B_Y2, rb + B_ST2});
+        ls = S.begin(lane, {rb + B_A1, R_WP + i}, {rb + B_Y2, rb + B_ST2, R_SK + i});
       } else if (n.in_prefix == 0) {
-        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG, R_WP + i}, {rb + B_Y1, rb + B_ST1}); }
-        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN, R_WP + i}, {rb + B_Y1, rb + B_ST1}); }
+        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG, R_WP + i}, {rb + B_Y1, rb + B_ST1, R_SK + i}); }
+        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN, R_WP + i}, {rb + B_Y1, rb + B_ST1, R_SK + i}); }
       } else {
         d.src0 = AB(arena, P->X[i]); d.C0 = n.in_prefix * f; d.P0 = P->PX[i];
         d.src1 = AB(arena, n.up); d.C1 = NBF[i + 1]; d.P1 = NBF[i + 1];
         ls = S.begin(lane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
-                            n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, R_WP + i}, {rb + B_Y1, rb + B_ST1});
+                            n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, R_WP + i}, {rb + B_Y1, rb + B_ST1, R_SK + i});
       }
       d.wpack = wpack + (size_t)L.wf * es;
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
@@ -693,21 +711,21 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
   for (int k = (int)P->exec.size() - 1; k >= 0 && rc == NUNET_OK; --k) {
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
-    const int lane = i, wlane = 5 + i, rb = R_BLK + k * B_STRIDE, rl = R_LVL + i * L_STRIDE;
+    const int lane = lane_of(P, n), wlane = 5 + lane, rb = R_BLK + k * B_STRIDE, rl = R_LVL + k * L_STRIDE;
     if (!written[i][n.out_slot]) { nunet_set_error("plan_backward: internal: grad of x%d_%d never produced", n.i, n.j); rc = NUNET_EINVAL; break; }
     nunet_wgrad_desc wdesc[2]; int wrdy[2] = {-1, -1};
     for (int cv = 1; cv >= 0 && rc == NUNET_OK; --cv) {
       const ConvL& L = cv == 0 ? n.c1 : n.c2;
       const int cidx = 2 * k + cv;
       const int rdy = rl + (pp[i] ? L_DY1 : L_DY0);
-      char* dybuf = AB(arena, P->off_dy[i][pp[i]]);
+      char* dybuf = AB(arena, P->off_dy[k][pp[i]]);
       pp[i] ^= 1;
       // BN + ReLU backward
       nunet_bn_bwd_desc b; memset(&b, 0, sizeof(b));
       b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
       int rda, ry;
       if (cv == 1) { b.da = AB(arena, P->GX[i] + (size_t)n.out_slot * f * es); b.PDA = P->PX[i]; b.y = AB(arena, n.y2); rda = R_GX + i * 5 + n.out_slot; ry = rb + B_Y2; }
-      else { b.da = AB(arena, P->off_da1[i]); b.PDA = f; b.y = AB(arena, n.y1); rda = rl + L_DA1; ry = rb + B_Y1; }
+      else { b.da = AB(arena, P->off_da1[k]); b.PDA = f; b.y = AB(arena, n.y1); rda = rl + L_DA1; ry = rb + B_Y1; }
       b.PY = f; b.mean_invstd = save + L.save; b.gamma = params + L.g_off; b.beta = params + L.be_off;
       b.sums = bsums + L.bsum;
       float* gl = gsr + L.gs + 9LL * L.cout * L.cinpad;
@@ -739,17 +757,17 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
       d.src0 = b.dy; d.C0 = f; d.P0 = f;
       d.wpack = wpack + (size_t)L.wd * es;
       if (cv == 1) {
-        d.dst0 = AB(arena, P->off_da1[i]); d.D0 = f; d.Q0 = f;
-        ls = S.begin(lane, {rdy}, {rl + L_DA1});
+        d.dst0 = AB(arena, P->off_da1[k]); d.D0 = f; d.Q0 = f;
+        ls = S.begin(lane, {rdy}, {rl + L_DA1, R_SK + i});
       } else if (n.in_prefix == 0) {
-        d.dst0 = AB(arena, P->off_gpin[i]); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1];
-        ls = S.begin(lane, {rdy}, {rl + L_GPIN});
+        d.dst0 = AB(arena, P->off_gpin[k]); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1];
+        ls = S.begin(lane, {rdy}, {rl + L_GPIN, R_SK + i});
       } else {
         d.dst0 = AB(arena, P->GX[i]); d.D0 = n.in_prefix * f; d.Q0 = P->PX[i]; d.acc_slot_w = f;
         for (int q = 0; q < n.in_prefix; ++q) { if (written[i][q]) d.acc0_mask |= 1u << q; written[i][q] = true; }
-        d.dst1 = AB(arena, P->off_gup[i]); d.D1 = NBF[i + 1]; d.Q1 = NBF[i + 1];
+        d.dst1 = AB(arena, P->off_gup[k]); d.D1 = NBF[i + 1]; d.Q1 = NBF[i + 1];
         ls = S.begin(lane, {rdy}, {R_GX + i * 5 + 0, n.in_prefix > 1 ? R_GX + i * 5 + 1 : -1, n.in_prefix > 2 ? R_GX + i * 5 + 2 : -1,
-                                   n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP});
+                                   n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP, R_SK + i});
       }
       if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
       rc = nunet_conv3x3_fwd(&d, ls);
@@ -760,13 +778,13 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
           // through MaxPool2d(2,2) into x_{i-1,0}
           ls = S.begin(lane, {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0});
           rc = nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
-                                    AB(arena, P->off_gpin[i]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], written[i - 1][0] ? 1 : 0, ls);
+                                    AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], written[i - 1][0] ? 1 : 0, ls);
           S.end();
           written[i - 1][0] = true;
         } else {
           // through the bilinear upsample into x_{i+1,up_slot}
           ls = S.begin(lane, {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot});
-          rc = nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[i]), NBF[i + 1],
+          rc = nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
                                     AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], written[i + 1][n.up_slot] ? 1 : 0, ls);
           S.end();
           written[i + 1][n.up_slot] = true;
