@@ -576,14 +576,14 @@ struct WgP {
 };
 
 template <typename T> struct WgCfg {
-  static constexpr int NT = 256;
+  static constexpr int NT = 192;                      // 3 waves: wave w owns taps 3w..3w+2
   static constexpr int BM = 128, HPMAX = 192;
   static constexpr int EPV = Tr<T>::EPV;
   static constexpr bool F32 = std::is_same<T, float>::value;
   static constexpr int SR = 32;                       // row stride (elements): 32 channels, no pad
   static constexpr int UPP = 32 / EPV;                // 16-byte units per pixel row
-  static constexpr int NUD = BM * UPP / NT;           // dY units per thread
-  static constexpr int NUA = HPMAX * UPP / NT;        // halo units per thread
+  static constexpr int NUD = (BM * UPP + NT - 1) / NT;      // dY units per thread
+  static constexpr int NUA = (HPMAX * UPP + NT - 1) / NT;   // halo units per thread
   static constexpr int STAGE = (BM + HPMAX) * SR;     // elements per LDS stage
 };
 
@@ -598,15 +598,18 @@ template <> struct Frag16<bf16_t> { typedef bf16x8 V; };
 template <> struct Frag16<f16_t> { typedef f16x8 V; };
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
+// Work item = (32 Cout) x (32 Cin) x 9 taps of dW over a slice of the 128-pixel tiles. The three
+// waves of a workgroup split the TAPS (3 each) and all walk every pixel of the tile: no cross-wave
+// reduction, 48 accumulator registers per lane. Tiles are double-buffered in LDS; the next tile's
+// global loads are in flight (registers) while the current one multiplies.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {
+__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) {
   typedef WgCfg<T> C;
   constexpr int NT = C::NT, BM = C::BM, EPV = C::EPV, SR = C::SR, UPP = C::UPP;
   __shared__ __attribute__((aligned(16))) T s_stage[2 * C::STAGE];
   __shared__ int s_hidx[BM];
   __shared__ int s_mxy[BM];
   __shared__ int s_hxy[C::HPMAX];
-  __shared__ float s_red[3 * 16 * 64];   // cross-wave reduction, one tap at a time
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -640,12 +643,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {
   }
   __syncthreads();
 
-  // tile-invariant staging codes of this thread's units
+  // tile-invariant staging codes of this thread's units (-2: no such unit)
   int dcode[C::NUD], acode[C::NUA];
 #pragma unroll
-  for (int k = 0; k < C::NUD; ++k) dcode[k] = s_mxy[(tid + k * NT) / UPP];
+  for (int k = 0; k < C::NUD; ++k) { const int u = tid + k * NT; dcode[k] = u < BM * UPP ? s_mxy[u / UPP] : -2; }
 #pragma unroll
-  for (int k = 0; k < C::NUA; ++k) acode[k] = s_hxy[(tid + k * NT) / UPP];
+  for (int k = 0; k < C::NUA; ++k) { const int u = tid + k * NT; acode[k] = u < C::HPMAX * UPP ? s_hxy[u / UPP] : -2; }
   // the channel slice of the forward input this item reads: one source per 16-byte unit
   // (C0 is a multiple of 16, so a unit never straddles the two concat sources)
   const int seg = tid % UPP;                 // same for all units of a thread (NT % UPP == 0)
@@ -684,21 +687,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {
     T* sd = s_stage + buf * C::STAGE;
     T* sa = sd + BM * SR;
 #pragma unroll
-    for (int k = 0; k < C::NUD; ++k) st16(&sd[((tid + k * NT) / UPP) * SR + seg * EPV], dreg[k]);
+    for (int k = 0; k < C::NUD; ++k) if (dcode[k] != -2) st16(&sd[((tid + k * NT) / UPP) * SR + seg * EPV], dreg[k]);
 #pragma unroll
-    for (int k = 0; k < C::NUA; ++k) st16(&sa[((tid + k * NT) / UPP) * SR + seg * EPV], areg[k]);
+    for (int k = 0; k < C::NUA; ++k) if (acode[k] != -2) st16(&sa[((tid + k * NT) / UPP) * SR + seg * EPV], areg[k]);
   };
 
-  f32x16 acc[9];
+  f32x16 acc[3];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // per-lane LDS offsets of this wave's pixels (tile-invariant)
-  int toff[9];
+  // this wave's three taps: rows 3w..3w+2 of the 3x3 window = kernel row `wave`
+  int toff[3];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) toff[tap] = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * SR;
+  for (int t = 0; t < 3; ++t) toff[t] = ((wave - 1) * HW2 + (t - 1)) * SR;
 
   int mt = split;
   if (mt < p.nMT) load_tile(mt);
@@ -711,34 +714,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {
     const T* sd = s_stage + buf * C::STAGE;
     const T* sa = sd + BM * SR;
     if constexpr (C::F32) {
-      // wave w owns pixels [32w, 32w+32): 16 k-steps of 2 pixels (lane half h picks the pixel)
 #pragma unroll 4
-      for (int kk = 0; kk < 16; ++kk) {
-        const int m = wave * 32 + kk * 2 + h;
+      for (int kk = 0; kk < BM / 2; ++kk) {
+        const int m = kk * 2 + h;
         const float av = sd[m * SR + r];
         const int hx = s_hidx[m] * SR + r;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sa[hx + toff[tap]], acc[tap], 0, 0, 0);
+        for (int t = 0; t < 3; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sa[hx + toff[t]], acc[t], 0, 0, 0);
       }
     } else {
       typedef typename Frag16<T>::V FV;
       const int q = (lane >> 2) & 3;                             // row within the 4-row block
       const int colo = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);  // column offset supplied by this lane
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int m0 = wave * 32 + kk * 16 + 8 * h + q, m1 = m0 + 4;
+      for (int kk = 0; kk < BM / 16; ++kk) {
+        const int m0 = kk * 16 + 8 * h + q, m1 = m0 + 4;
         const int b0 = s_hidx[m0] * SR + colo, b1 = s_hidx[m1] * SR + colo;
         const s16x4 a0 = tr_read(&sd[m0 * SR + colo]);
         const s16x4 a1 = tr_read(&sd[m1 * SR + colo]);
         const s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-        s16x4 x0[9], x1[9];
+        s16x4 x0[3], x1[3];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) { x0[tap] = tr_read(&sa[b0 + toff[tap]]); x1[tap] = tr_read(&sa[b1 + toff[tap]]); }
+        for (int t = 0; t < 3; ++t) { x0[t] = tr_read(&sa[b0 + toff[t]]); x1[t] = tr_read(&sa[b1 + toff[t]]); }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const s16x8 bv = __builtin_shufflevector(x0[tap], x1[tap], 0, 1, 2, 3, 4, 5, 6, 7);
-          Mma<T>::mma(acc[tap], __builtin_bit_cast(FV, av), __builtin_bit_cast(FV, bv));
+        for (int t = 0; t < 3; ++t) {
+          const s16x8 bv = __builtin_shufflevector(x0[t], x1[t], 0, 1, 2, 3, 4, 5, 6, 7);
+          Mma<T>::mma(acc[t], __builtin_bit_cast(FV, av), __builtin_bit_cast(FV, bv));
         }
       }
     }
@@ -748,24 +750,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgP p) {
     mt = nmt;
   }
 
-  // cross-wave reduction (one tap at a time through LDS), then one atomic per output element
+  // one atomic per output element of this wave's three taps
   const int ci = ci0 + r;
+  if (ci < p.Cin) {
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    if (wave > 0) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s_red[((wave - 1) * 16 + i) * 64 + lane] = acc[tap][i];
-    }
-    __syncthreads();
-    if (wave == 0 && ci < p.Cin) {
+    for (int t = 0; t < 3; ++t) {
+      const int tap = wave * 3 + t;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float v = acc[tap][i] + s_red[(0 * 16 + i) * 64 + lane] + s_red[(1 * 16 + i) * 64 + lane] + s_red[(2 * 16 + i) * 64 + lane];
         const int co = co0 + acc_row(i, h);
-        if (co < p.Cout) atomicAdd(&p.dw[((size_t)tap * p.Cout + co) * p.Cin + ci], v);
+        if (co < p.Cout) atomicAdd(&p.dw[((size_t)tap * p.Cout + co) * p.Cin + ci], acc[t][i]);
       }
     }
-    __syncthreads();
   }
 }
 
@@ -782,7 +778,7 @@ template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStre
   p.nMT = g.tilesX * g.tilesY * g.tilesG;
   const int otiles = p.nCoT * p.nCiT;
   static int wg_target = 0;
-  if (!wg_target) { const char* e = getenv("NUNET_WG_TARGET"); wg_target = e ? atoi(e) : 320; }
+  if (!wg_target) { const char* e = getenv("NUNET_WG_TARGET"); wg_target = e ? atoi(e) : 256; }
   int ks = ceil_div(wg_target, otiles);
   if (ks > p.nMT) ks = p.nMT;
   if (ks < 1) ks = 1;
