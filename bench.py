@@ -135,7 +135,10 @@ def main():
 
     roofline = None
     if not args.no_roofline and rank == 0:
-        # live per-kernel timing: the same step, eager, hipEvents around every launch
+        # live per-kernel timing: the same step, eager, hipEvents around every launch on its launch
+        # stream; single-lane issue for this pass so that kernels are timed alone (the timed region
+        # above runs the lanes concurrently)
+        L.check(L.lib().nunet_plan_set_multistream(ts.pl.handle, 0), "set_multistream")
         for _ in range(2):
             ts._fwd_bwd(); ts._allreduce(); ts._opt()
         torch.cuda.synchronize()
@@ -159,6 +162,21 @@ def main():
         else:
             roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}
+        # HBM traffic of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction,
+        # MI355X_MICROARCH.md "HBM"): bytes per launch, averaged over its launches in a step
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pat = {"conv3x3_fwd_dgrad<BM128,BN64>": "void conv3x3_kernel<", "conv3x3_fwd_dgrad<BM256,BN32>": "Li4ELi1ELi2ELi1ELb0",
+                   "conv3x3_wgrad(Cout>=64)": "wgrad_kernel", "conv3x3_wgrad(Cout=32)": "wgrad_kernel"}.get(top["name"])
+            if pat and args.dtype == "bf16" and hw == 96 and n == 16:
+                for kname, rec in pmc.items():
+                    if pat in kname and "DF16b" in kname or (pat == "void conv3x3_kernel<" and kname.startswith(pat)):
+                        roofline["traffic"] = rec["hbm_bytes_per_launch_corrected"]
+                        roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                        roofline["algorithmic_bytes_per_launch"] = top["bytes"] / top["launches"]
+                        break
+        except Exception:
+            pass
         roofline["kernel"] = top["name"]
         roofline["avg_launch_us"] = avg_ms * 1e3
         roofline["launches_per_step"] = top["launches"] / reps

@@ -4,6 +4,8 @@
 //   1x1 heads fwd/bwd, BCEDiceLoss fwd/bwd, IoU counts, SGD, layout helpers.
 // Reference arithmetic: finished/archs1.py:17-21,82-83,105-111; losses.py:103-117;
 // metrics.py:6-18; trains.py:229-231.
+#include <stdlib.h>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -321,6 +323,16 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
   }
 }
 
+static int bn_bwd_ipb() {
+  static int v = 0;
+  if (!v) { const char* e = getenv("NUNET_BN_IPB"); v = e ? atoi(e) : 8; }
+  return v;
+}
+static int bn_bwd_cap(bool apply) {
+  static int cr = 0, ca = 0;
+  if (!cr) { const char* e = getenv("NUNET_BNR_CAP"); cr = e ? atoi(e) : 512; e = getenv("NUNET_BNA_CAP"); ca = e ? atoi(e) : 1024; }
+  return apply ? ca : cr;
+}
 template <typename T, bool APPLY> static int launch_bn_bwd_t(const nunet_bn_bwd_desc* d, hipStream_t st) {
   BnBwdP p;
   p.da = d->da; p.PDA = d->PDA; p.y = d->y; p.PY = d->PY; p.mi = d->mean_invstd; p.gamma = d->gamma; p.beta = d->beta;
@@ -331,7 +343,7 @@ template <typename T, bool APPLY> static int launch_bn_bwd_t(const nunet_bn_bwd_
   // fewer, fatter blocks: each block ends with 2C global atomics
   ProfScope ps(APPLY ? PC_BN_BWD_APPLY : PC_BN_BWD_REDUCE, 0, (double)np * d->C * sizeof(T) * (APPLY ? 3.0 : 2.0), st);
   // fat blocks: every block ends with C (2C) same-address global atomics
-  hipLaunchKernelGGL((bn_relu_bwd_kernel<T, APPLY>), dim3(grid_for(np, (256 / G) * 8, APPLY ? 1024 : 512)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((bn_relu_bwd_kernel<T, APPLY>), dim3(grid_for(np, (256 / G) * bn_bwd_ipb(), bn_bwd_cap(APPLY))), dim3(256), 0, st, p);
   return nunet_check_launch(APPLY ? "bn_relu_bwd_apply" : "bn_relu_bwd_reduce");
 }
 template <typename T> static int launch_bn_bwd_reduce(const nunet_bn_bwd_desc* d, hipStream_t st) { return launch_bn_bwd_t<T, false>(d, st); }
@@ -597,44 +609,54 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int PX, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx, int PDX, int accumulate, float* __restrict__ dw, float* __restrict__ db, int N, int H, int W, int C, int K) {
-  // C must be 32: lane&31 = channel; the 8 half-waves of a block walk disjoint pixels
-  __shared__ float s_w[8][HEAD_MAXK][33];
-  const int c = threadIdx.x & 31;
-  const int hwv = threadIdx.x >> 5;  // half-wave in block
-  const int nhw = blockDim.x >> 5;
-  float wk[HEAD_MAXK], aw[HEAD_MAXK], ab[HEAD_MAXK];
+  // C == 32. A thread owns one 16-byte channel group (EPV channels) of a pixel; G = 32/EPV threads
+  // cover a pixel. dW/db partials live in registers and meet through LDS once per block.
+  constexpr int EPV = Tr<T>::EPV;
+  constexpr int G = 32 / EPV;
+  __shared__ float s_dw[HEAD_MAXK * 32 + HEAD_MAXK];
+  for (int i = threadIdx.x; i < HEAD_MAXK * 33; i += blockDim.x) s_dw[i] = 0.f;
+  __syncthreads();
+  const int cg = threadIdx.x % G, pl = threadIdx.x / G, ppb = blockDim.x / G;
+  float wk[HEAD_MAXK][EPV], aw[HEAD_MAXK][EPV], ab[HEAD_MAXK];
 #pragma unroll
-  for (int k = 0; k < HEAD_MAXK; ++k) { wk[k] = k < K ? w[k * C + c] : 0.f; aw[k] = 0.f; ab[k] = 0.f; }
+  for (int k = 0; k < HEAD_MAXK; ++k) {
+    ab[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { wk[k][e] = k < K ? w[k * C + cg * EPV + e] : 0.f; aw[k][e] = 0.f; }
+  }
   const int64_t hw = (int64_t)H * W, npix = (int64_t)N * hw;
-  for (int64_t pix = (int64_t)blockIdx.x * nhw + hwv; pix < npix; pix += (int64_t)gridDim.x * nhw) {
+  for (int64_t pix = (int64_t)blockIdx.x * ppb + pl; pix < npix; pix += (int64_t)gridDim.x * ppb) {
     const int n = (int)(pix / hw);
     const int64_t rem = pix - n * hw;
-    const float xv = to_f32(x[pix * PX + c]);
-    float g = 0.f;
+    const Vec16<T> xv = ld16(x + pix * PX + cg * EPV);
+    float g[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) g[e] = 0.f;
 #pragma unroll
     for (int k = 0; k < HEAD_MAXK; ++k) {
       if (k < K) {
         const float d = dl[((int64_t)n * K + k) * hw + rem];
-        g += d * wk[k];
-        aw[k] += d * xv;
-        ab[k] += d;
+        if (cg == 0) ab[k] += d;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { g[e] += d * wk[k][e]; aw[k][e] += d * xv.get(e); }
       }
     }
     if (dx) {
-      T* q = dx + pix * PDX + c;
-      *q = from_f32<T>(accumulate ? to_f32(*q) + g : g);
+      T* q = dx + pix * PDX + cg * EPV;
+      Vec16<T> o = accumulate ? ld16(q) : zero16<T>();
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o.set(e, (accumulate ? o.get(e) : 0.f) + g[e]);
+      st16(q, o);
     }
   }
+  for (int k = 0; k < K; ++k) {
 #pragma unroll
-  for (int k = 0; k < HEAD_MAXK; ++k) { s_w[hwv][k][c] = aw[k]; if (c == 0) s_w[hwv][k][32] = ab[k]; }
-  __syncthreads();
-  for (int t = threadIdx.x; t < K * 33; t += blockDim.x) {
-    const int k = t / 33, cc = t - k * 33;
-    float sum = 0.f;
-    for (int q = 0; q < nhw; ++q) sum += s_w[q][k][cc];
-    if (cc < 32) atomicAdd(&dw[k * C + cc], sum);
-    else atomicAdd(&db[k], sum);
+    for (int e = 0; e < EPV; ++e) atomicAdd(&s_dw[k * 32 + cg * EPV + e], aw[k][e]);
+    if (cg == 0) atomicAdd(&s_dw[HEAD_MAXK * 32 + k], ab[k]);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * 32; i += blockDim.x) atomicAdd(&dw[i], s_dw[i]);
+  if (threadIdx.x < K) atomicAdd(&db[threadIdx.x], s_dw[HEAD_MAXK * 32 + threadIdx.x]);
 }
 template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* b, float* logits, hipStream_t st) {
   ProfScope ps(PC_HEAD, 2.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) + K * 4), st);
@@ -643,7 +665,7 @@ template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int
 }
 template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw, float* db, hipStream_t st) {
   ProfScope ps(PC_HEAD, 4.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) * (acc ? 3 : 2) + K * 4), st);
-  hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 8 * 16, 512)), dim3(256), 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw, db, N, H, W, C, K);
+  hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, (256 / (32 / Tr<T>::EPV)) * 8, 256)), dim3(256), 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw, db, N, H, W, C, K);
   return nunet_check_launch("head_bwd");
 }
 extern "C" int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* b, float* logits, nunet_stream_t s) {
@@ -755,13 +777,20 @@ __global__ __launch_bounds__(256) void loss_step_partial_kernel(const float* __r
   a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o); cu += __shfl_xor(cu, o); }
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ float s_f[4][4];
+  __shared__ unsigned s_c[4][2];
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_f[wv][0] = a0; s_f[wv][1] = a1; s_f[wv][2] = a2; s_f[wv][3] = a3; s_c[wv][0] = ci; s_c[wv][1] = cu; }
+  __syncthreads();
+  if (threadIdx.x < 4) {   // one atomic per block per quantity (same-address atomics serialise)
     float* w = ws + (size_t)hd * ws_stride;
-    atomicAdd(&w[n * 3 + 0], a0); atomicAdd(&w[n * 3 + 1], a1); atomicAdd(&w[n * 3 + 2], a2); atomicAdd(&w[N * 3], a3);
-    if (last) {
-      unsigned long long* cnt = (unsigned long long*)(ws + (size_t)heads * ws_stride);
-      atomicAdd(&cnt[0], (unsigned long long)ci); atomicAdd(&cnt[1], (unsigned long long)cu);
-    }
+    const float v = s_f[0][threadIdx.x] + s_f[1][threadIdx.x] + s_f[2][threadIdx.x] + s_f[3][threadIdx.x];
+    if (threadIdx.x < 3) atomicAdd(&w[n * 3 + threadIdx.x], v);
+    else atomicAdd(&w[N * 3], v);
+  } else if (last && threadIdx.x < 6) {
+    const int k = threadIdx.x - 4;
+    unsigned long long* cnt = (unsigned long long*)(ws + (size_t)heads * ws_stride);
+    atomicAdd(&cnt[k], (unsigned long long)(s_c[0][k] + s_c[1][k] + s_c[2][k] + s_c[3][k]));
   }
 }
 __global__ __launch_bounds__(256) void loss_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, const float* __restrict__ ws, int ws_stride, int N, int heads, float* __restrict__ dx, float* __restrict__ loss_out, double* __restrict__ meters) {
