@@ -173,6 +173,14 @@ size_t nunet_loss_step_ws_bytes(int32_t N, int32_t heads);
 int nunet_loss_step(const float* logits, const float* target, int32_t N, int64_t per_sample,
                     int32_t heads, float* ws, float* dlogits, float* loss_out, double* meters,
                     nunet_stream_t s);
+/* LovaszHingeLoss (losses.py:49-96,120-129; per_image=True, mean over images). logits/target: [N][per_image]
+ * (num_classes must be 1: the reference squeezes dim 1). Per-image sort in LDS: per_image <= 16384.
+ * dlogits_unit receives d loss / d logits for an upstream gradient of 1; _bwd scales it by gscale[0]. */
+size_t nunet_lovasz_ws_bytes(int32_t N);
+int nunet_lovasz_hinge_fwd(const float* logits, const float* target, int32_t N, int64_t per_image,
+                           float* ws, float* dlogits_unit, float* loss, nunet_stream_t s);
+int nunet_lovasz_hinge_bwd(const float* dlogits_unit, const float* gscale, int64_t n, float* dlogits,
+                           nunet_stream_t s);
 /* counts[0] += |A&B|, counts[1] += |A|B|, A = logits>0, B = target>0.5 */
 int nunet_iou_counts(const float* logits, const float* target, int64_t n,
                      unsigned long long* counts, nunet_stream_t s);

@@ -5,7 +5,7 @@ from torch import nn
 
 from . import _lib as L
 
-__all__ = ['BCEDiceLoss']
+__all__ = ['BCEDiceLoss', 'LovaszHingeLoss']
 
 
 class _BCEDiceFn(torch.autograd.Function):
@@ -43,3 +43,43 @@ class BCEDiceLoss(nn.Module):
 
     def forward(self, input, target):
         return _BCEDiceFn.apply(input.contiguous(), target.contiguous())
+
+
+class _LovaszFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        L.require_gpu_tensor(logits, torch.float32, "logits")
+        L.require_gpu_tensor(target, torch.float32, "target")
+        if logits.shape != target.shape or logits.dim() != 3:
+            raise L.NunetError("LovaszHingeLoss: expected [N,H,W] logits and target, got %s / %s"
+                               % (tuple(logits.shape), tuple(target.shape)))
+        n = logits.size(0)
+        per = logits.numel() // n
+        ws = torch.empty(n, dtype=torch.float32, device=logits.device)
+        unit = torch.empty_like(logits)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        L.check(L.lib().nunet_lovasz_hinge_fwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.ptr(unit), L.ptr(loss),
+                                               L.stream()), "nunet_lovasz_hinge_fwd")
+        ctx.save_for_backward(unit)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (unit,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        dx = torch.empty_like(unit)
+        L.check(L.lib().nunet_lovasz_hinge_bwd(L.ptr(unit), L.ptr(g), unit.numel(), L.ptr(dx), L.stream()),
+                "nunet_lovasz_hinge_bwd")
+        return dx, None
+
+
+class LovaszHingeLoss(nn.Module):
+    """reference losses.py:120-129 (lovasz_hinge(per_image=True) of the channel-squeezed tensors)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, input, target):
+        input = input.squeeze(1)
+        target = target.squeeze(1)
+        return _LovaszFn.apply(input.contiguous(), target.contiguous())

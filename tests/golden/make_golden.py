@@ -245,3 +245,24 @@ def run_training_log(epochs=6, train_size=256, val_size=64, bs=16, hw=96, lr=1e-
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "trainlog":
     torch.set_num_threads(8)
     run_training_log()
+
+
+def run_lovasz():
+    """LovaszHingeLoss goldens (losses.py:49-96,120-129), per_image=True as the reference module calls it."""
+    rng = np.random.default_rng(17)
+    out = {}
+    for tag, shape in (("a", (3, 1, 24, 40)), ("b", (2, 1, 96, 96)), ("c", (2, 1, 8, 8))):
+        x = torch.from_numpy((rng.standard_normal(shape) * 2).astype(np.float32)).requires_grad_(True)
+        t = torch.from_numpy((rng.random(shape) > 0.7).astype(np.float32))
+        if tag == "c":
+            t[1] = 0          # an image without any positive pixel
+        loss = ref_losses.LovaszHingeLoss()(x, t)
+        loss.backward()
+        out["x_" + tag] = x.detach().numpy(); out["t_" + tag] = t.numpy()
+        out["loss_" + tag] = np.float64(loss.item()); out["dx_" + tag] = x.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "lovasz.npz"), **out)
+    print("lovasz ok", [float(out["loss_" + k]) for k in "abc"])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "lovasz":
+    run_lovasz()

@@ -418,3 +418,19 @@ def test_conv3x3_splitk_slabs(dt):
             np.testing.assert_allclose(stats[:cout].cpu().numpy() / m, got.sum((0, 2, 3)).numpy() / m, atol=1e-4)
             outs.append(y.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_lovasz_hinge_against_reference_goldens():
+    """LovaszHingeLoss on device vs the reference's own outputs."""
+    from conftest import load_golden
+    g = load_golden("lovasz")
+    crit = nunet_amd.losses.LovaszHingeLoss()
+    for tag in ("a", "b", "c"):
+        x = torch.from_numpy(g["x_" + tag]).to(DEV).requires_grad_(True)
+        t = torch.from_numpy(g["t_" + tag]).to(DEV)
+        loss = crit(x, t)
+        (loss * 0.5).backward()
+        assert abs(float(loss.detach()) - float(g["loss_" + tag])) < 2e-5 * max(1.0, float(g["loss_" + tag])), tag
+        np.testing.assert_allclose(x.grad.cpu().numpy() * 2, g["dx_" + tag], atol=2e-7, rtol=2e-4, err_msg=tag)
+    with pytest.raises(L.NunetError):
+        crit(torch.zeros(1, 1, 256, 256, device=DEV), torch.zeros(1, 1, 256, 256, device=DEV))   # > 16384 px: refused loudly

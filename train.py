@@ -37,7 +37,7 @@ def parse_args():
     p.add_argument('--num_classes', default=1, type=int)
     p.add_argument('--input_w', default=96, type=int)
     p.add_argument('--input_h', default=96, type=int)
-    p.add_argument('--loss', default='BCEDiceLoss', choices=LOSS_NAMES)
+    p.add_argument('--loss', default='BCEDiceLoss', choices=LOSS_NAMES)   # LovaszHingeLoss runs the generic autograd path
     p.add_argument('--dataset', default='synthetic_blobs')
     p.add_argument('--optimizer', default='SGD', choices=['Adam', 'SGD'])
     p.add_argument('--lr', '--learning_rate', default=1e-3, type=float)
@@ -105,7 +105,7 @@ def main():
     val = tuple(v.cuda() for v in make_split(config['val_size'], h, w, config['input_channels'], config['num_classes'], 2000))
     steps = config['train_size'] // bs          # drop_last=True (trains.py:296)
 
-    fused = config['optimizer'] == 'SGD'
+    fused = config['optimizer'] == 'SGD' and config['loss'] == 'BCEDiceLoss'   # TrainStep fuses BCEDice; other losses go through autograd
     if fused:
         model.train()
         ts = TrainStep(model, (bs, config['input_channels'], h, w), lr=config['lr'], momentum=config['momentum'],
@@ -113,7 +113,11 @@ def main():
         ts.capture(train[0][:bs], train[1][:bs])
     else:
         params = filter(lambda p: p.requires_grad, model.parameters())
-        optimizer = torch.optim.Adam(params, lr=config['lr'], weight_decay=config['weight_decay'])
+        if config['optimizer'] == 'Adam':
+            optimizer = torch.optim.Adam(params, lr=config['lr'], weight_decay=config['weight_decay'])
+        else:
+            optimizer = torch.optim.SGD(params, lr=config['lr'], momentum=config['momentum'], nesterov=config['nesterov'],
+                                        weight_decay=config['weight_decay'])
 
     log = OrderedDict([(k, []) for k in ('epoch', 'lr', 'loss', 'iou', 'val_loss', 'val_iou', 'images_per_sec')])
     best_iou, trigger = 0, 0
