@@ -150,10 +150,14 @@ int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t
 int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K,
                    const void* x, int32_t PX, const float* w, const float* b,
                    float* logits, nunet_stream_t s);
+/* dx (+)= dlogits . w ; parameter gradients come back as `nslabs` partial slabs, one per workgroup:
+ * dw_slabs[s][K*C + K] = [weights grad | bias grad] of slab s (fully overwritten); the caller sums the
+ * slabs (the plan's unpack kernel does). No atomics: same-address float atomics from hundreds of
+ * workgroups cost more than the whole kernel. */
 int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K,
                    const void* x, int32_t PX, const float* w, const float* dlogits,
                    void* dx, int32_t PDX, int32_t accumulate,
-                   float* dw, float* db, nunet_stream_t s);
+                   float* dw_slabs, int32_t nslabs, nunet_stream_t s);
 
 /* ------------------------------------------------------------------------ */
 /* BCEDiceLoss (losses.py:103-117), iou_score (metrics.py:6-18)              */

@@ -85,7 +85,7 @@ _SIG = {
     "nunet_upsample2x_fwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp]),
     "nunet_upsample2x_bwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _i32, _vp]),
     "nunet_head_fwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _vp]),
-    "nunet_head_bwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "nunet_head_bwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "nunet_bce_dice_ws_bytes": (C.c_size_t, [_i32]),
     "nunet_bce_dice_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "nunet_bce_dice_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),

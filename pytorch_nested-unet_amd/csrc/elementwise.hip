@@ -607,34 +607,37 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
       if (k < K) logits[((int64_t)n * K + k) * hw + rem] = acc[k] + b[k];
   }
 }
-template <typename T>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int PX, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx, int PDX, int accumulate, float* __restrict__ dw, float* __restrict__ db, int N, int H, int W, int C, int K) {
+template <typename T, int KT>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int PX, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx, int PDX, int accumulate, float* __restrict__ dw, int N, int H, int W, int C, int K) {
   // C == 32. A thread owns one 16-byte channel group (EPV channels) of a pixel; G = 32/EPV threads
-  // cover a pixel. dW/db partials live in registers and meet through LDS once per block.
+  // cover a pixel. dW/db partials live in registers (KT = compile-time class count, 0 = generic)
+  // and meet through LDS once per block.
   constexpr int EPV = Tr<T>::EPV;
   constexpr int G = 32 / EPV;
+  constexpr int KM = KT > 0 ? KT : HEAD_MAXK;
   __shared__ float s_dw[HEAD_MAXK * 32 + HEAD_MAXK];
   for (int i = threadIdx.x; i < HEAD_MAXK * 33; i += blockDim.x) s_dw[i] = 0.f;
   __syncthreads();
   const int cg = threadIdx.x % G, pl = threadIdx.x / G, ppb = blockDim.x / G;
-  float wk[HEAD_MAXK][EPV], aw[HEAD_MAXK][EPV], ab[HEAD_MAXK];
+  float wk[KM][EPV], aw[KM][EPV], ab[KM];
 #pragma unroll
-  for (int k = 0; k < HEAD_MAXK; ++k) {
+  for (int k = 0; k < KM; ++k) {
     ab[k] = 0.f;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { wk[k][e] = k < K ? w[k * C + cg * EPV + e] : 0.f; aw[k][e] = 0.f; }
   }
-  const int64_t hw = (int64_t)H * W, npix = (int64_t)N * hw;
+  const int hw = H * W;
+  const int64_t npix = (int64_t)N * hw;
   for (int64_t pix = (int64_t)blockIdx.x * ppb + pl; pix < npix; pix += (int64_t)gridDim.x * ppb) {
-    const int n = (int)(pix / hw);
-    const int64_t rem = pix - n * hw;
+    const int n = (int)((unsigned)pix / (unsigned)hw);      // npix < 2^31 (checked on the host)
+    const int rem = (int)pix - n * hw;
     const Vec16<T> xv = ld16(x + pix * PX + cg * EPV);
     float g[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) g[e] = 0.f;
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXK; ++k) {
-      if (k < K) {
+    for (int k = 0; k < KM; ++k) {
+      if (KT > 0 || k < K) {
         const float d = dl[((int64_t)n * K + k) * hw + rem];
         if (cg == 0) ab[k] += d;
 #pragma unroll
@@ -649,23 +652,31 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
       st16(q, o);
     }
   }
-  for (int k = 0; k < K; ++k) {
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) atomicAdd(&s_dw[k * 32 + cg * EPV + e], aw[k][e]);
-    if (cg == 0) atomicAdd(&s_dw[HEAD_MAXK * 32 + k], ab[k]);
+  for (int k = 0; k < KM; ++k) {
+    if (k < K) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) atomicAdd(&s_dw[k * 32 + cg * EPV + e], aw[k][e]);
+      if (cg == 0) atomicAdd(&s_dw[HEAD_MAXK * 32 + k], ab[k]);
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < K * 32; i += blockDim.x) atomicAdd(&dw[i], s_dw[i]);
-  if (threadIdx.x < K) atomicAdd(&db[threadIdx.x], s_dw[HEAD_MAXK * 32 + threadIdx.x]);
+  // per-block slab [K*32 weights | K biases]: plain stores, summed by the caller (no same-address atomics)
+  float* slab = dw + (size_t)blockIdx.x * (K * 33);
+  for (int i = threadIdx.x; i < K * 32; i += blockDim.x) slab[i] = s_dw[i];
+  if (threadIdx.x < K) slab[K * 32 + threadIdx.x] = s_dw[HEAD_MAXK * 32 + threadIdx.x];
 }
 template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* b, float* logits, hipStream_t st) {
   ProfScope ps(PC_HEAD, 2.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) + K * 4), st);
   hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 256)), dim3(256), 0, st, (const T*)x, PX, w, b, logits, N, H, W, C, K);
   return nunet_check_launch("head_fwd");
 }
-template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw, float* db, hipStream_t st) {
+template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw_slabs, int nslabs, hipStream_t st) {
   ProfScope ps(PC_HEAD, 4.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) * (acc ? 3 : 2) + K * 4), st);
-  hipLaunchKernelGGL((head_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, (256 / (32 / Tr<T>::EPV)) * 8, 256)), dim3(256), 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw, db, N, H, W, C, K);
+  const dim3 grid(nslabs), blk(256);
+#define NUNET_HB(KT) hipLaunchKernelGGL((head_bwd_kernel<T, KT>), grid, blk, 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw_slabs, N, H, W, C, K)
+  if (K == 1) NUNET_HB(1); else if (K == 2) NUNET_HB(2); else if (K == 4) NUNET_HB(4); else NUNET_HB(0);
+#undef NUNET_HB
   return nunet_check_launch("head_bwd");
 }
 extern "C" int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* b, float* logits, nunet_stream_t s) {
@@ -674,10 +685,11 @@ extern "C" int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, in
   NUNET_REQUIRE(PX % (16 / dtype_size(dtype)) == 0, "head_fwd: pitch");
   return NUNET_DISPATCH(dtype, launch_head_fwd, N, H, W, C, K, x, PX, w, b, logits, (hipStream_t)s);
 }
-extern "C" int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* dlogits, void* dx, int32_t PDX, int32_t accumulate, float* dw, float* db, nunet_stream_t s) {
-  NUNET_REQUIRE(x && w && dlogits && dw && db, "head_bwd: null pointer");
+extern "C" int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* dlogits, void* dx, int32_t PDX, int32_t accumulate, float* dw_slabs, int32_t nslabs, nunet_stream_t s) {
+  NUNET_REQUIRE(x && w && dlogits && dw_slabs && nslabs >= 1 && nslabs <= 4096, "head_bwd: bad args");
   NUNET_REQUIRE(C == 32 && K >= 1 && K <= HEAD_MAXK, "head_bwd: C=%d K=%d unsupported (C==32, K<=%d)", C, K, HEAD_MAXK);
-  return NUNET_DISPATCH(dtype, launch_head_bwd, N, H, W, C, K, x, PX, w, dlogits, dx, PDX, accumulate, dw, db, (hipStream_t)s);
+  NUNET_REQUIRE((int64_t)N * H * W < (1LL << 31), "head_bwd: too many pixels");
+  return NUNET_DISPATCH(dtype, launch_head_bwd, N, H, W, C, K, x, PX, w, dlogits, dx, PDX, accumulate, dw_slabs, nslabs, (hipStream_t)s);
 }
 
 // ---------------------------------------------------------------------------

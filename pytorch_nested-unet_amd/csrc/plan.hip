@@ -21,9 +21,10 @@ static const int NBF[5] = {32, 64, 128, 256, 512};  // archs1.py:78
 // batched weight pack / gradient unpack
 // ---------------------------------------------------------------------------
 #define MAXENT 40
+#define HEAD_SLABS 256
 struct PackEnt { long long src, wf, wd; int cout, cin, cinpad, pad_; };
 struct PackTab { int n; int ntiles; PackEnt e[MAXENT]; int tile0[MAXENT + 1]; };
-struct UnpackEnt { long long src, dst; int cout, cin, cinpad, taps, nvec, pad_; };
+struct UnpackEnt { long long src, dst; int cout, cin, cinpad, taps, nvec, nslab; };   // nslab > 1: sum of partial slabs (heads)
 struct UnpackTab { int n; int accumulate; UnpackEnt e[MAXENT]; };
 
 // One block per (layer, 32 Cout x 32 Cin tile): the OIHW rows of a tile are contiguous runs of
@@ -70,6 +71,32 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
   float* g = grads + en.dst;
   const long long nw = (long long)en.cout * en.cin * en.taps;
   const long long total = nw + (long long)en.nvec * en.cout;
+  if (en.nslab > 1) {
+    // 1x1 head: [nslab][cout*cin + cout] partial slabs (already OIHW order), summed by one block:
+    // thread = slab, wave shuffles + LDS across the 4 waves, a handful of elements in total
+    if (blockIdx.x != 0) return;
+    __shared__ float s_p[256];
+    const int tot = (int)total;                       // <= HEAD classes * 33 = 264
+    for (int e0 = 0; e0 < tot; e0 += 256) {
+      const int ne = min(256, tot - e0);
+      const int parts = 256 / ne;                     // threads per element
+      const int e = threadIdx.x % ne, part = threadIdx.x / ne;
+      float v = 0.f;
+      if (part < parts) {
+#pragma unroll 8
+        for (int sl = part; sl < en.nslab; sl += parts) v += dw[(long long)sl * total + e0 + e];
+      }
+      s_p[threadIdx.x] = part < parts ? v : 0.f;
+      __syncthreads();
+      if ((int)threadIdx.x < ne) {
+        float t = 0.f;
+        for (int q = 0; q < parts; ++q) t += s_p[q * ne + threadIdx.x];
+        g[e0 + threadIdx.x] = tab.accumulate ? g[e0 + threadIdx.x] + t : t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     float v;
     if (i < nw) {
@@ -116,7 +143,7 @@ extern "C" int nunet_unpack_wgrad(const float* dw, int32_t cout, int32_t cin, in
   NUNET_REQUIRE(dw && g && cout > 0 && cin > 0 && cin_pad >= cin, "unpack_wgrad: bad args");
   UnpackTab tab; memset(&tab, 0, sizeof(tab));
   tab.n = 1; tab.accumulate = accumulate;
-  tab.e[0].src = 0; tab.e[0].dst = 0; tab.e[0].cout = cout; tab.e[0].cin = cin; tab.e[0].cinpad = cin_pad; tab.e[0].taps = 9; tab.e[0].nvec = 0;
+  tab.e[0].src = 0; tab.e[0].dst = 0; tab.e[0].cout = cout; tab.e[0].cin = cin; tab.e[0].cinpad = cin_pad; tab.e[0].taps = 9; tab.e[0].nvec = 0; tab.e[0].nslab = 1;
   int gx = (int)ceil_div64(9LL * cout * cin, 256 * 4);
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
@@ -260,7 +287,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     Head h;
     h.w_off = po; po += (long long)cfg->num_classes * NBF[0];
     h.b_off = po; po += cfg->num_classes;
-    h.gs = gs; gs += (long long)cfg->num_classes * NBF[0] + cfg->num_classes;
+    h.gs = gs; gs += (long long)HEAD_SLABS * ((long long)cfg->num_classes * NBF[0] + cfg->num_classes);
     h.slot = unet ? 1 : (nheads == 4 ? k + 1 : 4);
     P->heads.push_back(h);
   }
@@ -315,7 +342,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     pe.src = c.w_off; pe.wf = c.wf; pe.wd = c.wd; pe.cout = c.cout; pe.cin = c.cin; pe.cinpad = c.cinpad;
     if (9LL * c.cout * c.cinpad > P->pack_maxn) P->pack_maxn = 9LL * c.cout * c.cinpad;
     UnpackEnt& ue = P->utab.e[P->utab.n++];
-    ue.src = c.gs; ue.dst = c.w_off; ue.cout = c.cout; ue.cin = c.cin; ue.cinpad = c.cinpad; ue.taps = 9; ue.nvec = 3;
+    ue.src = c.gs; ue.dst = c.w_off; ue.cout = c.cout; ue.cin = c.cin; ue.cinpad = c.cinpad; ue.taps = 9; ue.nvec = 3; ue.nslab = 1;
     if (9LL * c.cout * c.cin + 3 * c.cout > P->unpack_maxn) P->unpack_maxn = 9LL * c.cout * c.cin + 3 * c.cout;
   };
   for (size_t r = 0; r < P->reg.size(); ++r) { add_conv(P->exec[P->reg[r]].c1); add_conv(P->exec[P->reg[r]].c2); }
@@ -332,7 +359,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   }
   for (size_t k = 0; k < P->heads.size(); ++k) {
     UnpackEnt& ue = P->utab.e[P->utab.n++];
-    ue.src = P->heads[k].gs; ue.dst = P->heads[k].w_off; ue.cout = cfg->num_classes; ue.cin = NBF[0]; ue.cinpad = NBF[0]; ue.taps = 1; ue.nvec = 1;
+    ue.src = P->heads[k].gs; ue.dst = P->heads[k].w_off; ue.cout = cfg->num_classes; ue.cin = NBF[0]; ue.cinpad = NBF[0]; ue.taps = 1; ue.nvec = 1; ue.nslab = HEAD_SLABS;
   }
   PlanRt* rt = new PlanRt();
   rt->lanes_ok = true;
@@ -703,7 +730,7 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
     hipStream_t ls = S.begin(0, {R_X + h.slot, R_DLOGITS}, {R_GX + h.slot, R_GSV + 30 + (int)k});
     rc = nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
                         params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
-                        written[0][h.slot] ? 1 : 0, gsr + h.gs, gsr + h.gs + (long long)c.num_classes * NBF[0], ls);
+                        written[0][h.slot] ? 1 : 0, gsr + h.gs, HEAD_SLABS, ls);
     S.end();
     written[0][h.slot] = true;
   }

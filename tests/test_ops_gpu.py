@@ -320,13 +320,14 @@ def test_head(dt, k):
     assert rel_err(logits.cpu(), ref.detach()) < 2e-5
     ref.backward(dl.double())
     dxb = torch.zeros((n, h, w, 160), dtype=tdt(dt), device=DEV)
-    dw = torch.zeros(k * c, dtype=torch.float32, device=DEV)
-    db = torch.zeros(k, dtype=torch.float32, device=DEV)
+    nslabs = 64
+    slabs = torch.full((nslabs, k * c + k), 7.0, dtype=torch.float32, device=DEV)     # fully overwritten
     L.check(L.lib().nunet_head_bwd(dt, n, h, w, c, k, L.ptr(xb, 128 * es), 160, L.ptr(wt_g), L.ptr(dl_g),
-                                   L.ptr(dxb, 128 * es), 160, 0, L.ptr(dw), L.ptr(db), L.stream()), "head bwd")
+                                   L.ptr(dxb, 128 * es), 160, 0, L.ptr(slabs), nslabs, L.stream()), "head bwd")
     assert rel_err(to_nchw(dxb, c, off=128), xd.grad) < TOL[dt]
-    assert rel_err(dw.view(k, c).cpu(), wd_.grad.view(k, c)) < 1e-4
-    assert rel_err(db.cpu(), bd.grad) < 1e-4
+    tot = slabs.sum(0).cpu()
+    assert rel_err(tot[:k * c].view(k, c), wd_.grad.view(k, c)) < 1e-4
+    assert rel_err(tot[k * c:], bd.grad) < 1e-4
 
 
 def test_bce_dice_and_iou_against_reference_goldens():
