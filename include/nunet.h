@@ -201,6 +201,13 @@ int nunet_sgd_step(float* p, const float* g, float* mom, int64_t n, const float*
 /* ------------------------------------------------------------------------ */
 /* layout helpers                                                            */
 /* ------------------------------------------------------------------------ */
+/* Device-side input pipeline (reference dataset.py:66-74 + trains.py:258-259,266): uint8 HWC batch ->
+ * ((u/255 - mean[c]) / std[c]) * post_scale as NCHW fp32 (post_scale = 1/255 reproduces the reference's
+ * second division; masks: mean/std NULL, post_scale 1). aug (NULL = none): per sample
+ * rot90 count (bits 0-1, np.rot90 sense; needs H == W when odd) | hflip (bit 2) | vflip (bit 3). */
+int nunet_preprocess_u8(const uint8_t* u8_nhwc, int32_t N, int32_t H, int32_t W, int32_t C,
+                        const float* mean, const float* stdv, const int32_t* aug, float post_scale,
+                        float* out_nchw, nunet_stream_t s);
 /* NCHW fp32 -> NHWC dtype with channel padding (zeros) up to cpad */
 int nunet_nchw_to_nhwc(const float* x, int32_t N, int32_t C, int32_t H, int32_t W,
                        int32_t dtype, void* y, int32_t cpad, nunet_stream_t s);

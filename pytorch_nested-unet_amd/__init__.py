@@ -6,7 +6,7 @@ import it with importlib or through the `nunet_amd` alias module at the repo roo
     import nunet_amd
     model = nunet_amd.archs.NestedUNet(1, 3, False, dtype='bf16').cuda()
 """
-from . import _lib, archs, engine, losses, metrics, parallel, synth, utils  # noqa: F401
+from . import _lib, archs, dataset, engine, losses, metrics, parallel, synth, utils  # noqa: F401
 from .archs import NestedUNet, UNet  # noqa: F401
 from .losses import BCEDiceLoss  # noqa: F401
 from .metrics import iou_score  # noqa: F401

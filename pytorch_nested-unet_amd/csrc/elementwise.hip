@@ -74,6 +74,48 @@ extern "C" int nunet_nchw_to_nhwc(const float* x, int32_t N, int32_t C, int32_t 
 }
 
 // ---------------------------------------------------------------------------
+// Device-side input pipeline: what reference dataset.py:66-74 does on the host
+// after decoding — albumentations Normalize() (trains.py:266), the extra /255 (dataset.py:71),
+// HWC -> CHW (dataset.py:72) — plus the geometric augmentations of trains.py:258-259
+// (RandomRotate90 / Flip) applied per sample from host-drawn codes. Input stays uint8 over PCIe.
+//   aug[n] = rot90 count (bits 0-1, counter-clockwise like np.rot90) | hflip (bit 2) | vflip (bit 3)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t* __restrict__ u, int N, int H, int W, int C,
+                                                             const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                             const int32_t* __restrict__ aug, float post_scale, float* __restrict__ out) {
+  const int64_t total = (int64_t)N * C * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    int64_t t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    // destination (y, x) <- source (sy, sx): undo flips, then the rotation
+    int sy = y, sx = x;
+    const int a = aug ? aug[n] : 0;
+    if (a & 8) sy = H - 1 - sy;
+    if (a & 4) sx = W - 1 - sx;
+    const int k = a & 3;                       // out = rot90(src, k)  (H == W when k is odd)
+    int ry = sy, rx = sx;
+    if (k == 1) { ry = sx; rx = W - 1 - sy; }
+    else if (k == 2) { ry = H - 1 - sy; rx = W - 1 - sx; }
+    else if (k == 3) { ry = H - 1 - sx; rx = sy; }
+    const float v = (float)u[(((int64_t)n * H + ry) * W + rx) * C + c];
+    const float m = mean ? mean[c] : 0.f, sd = stdv ? stdv[c] : 1.f;
+    out[i] = ((v / 255.f - m) / sd) * post_scale;
+  }
+}
+extern "C" int nunet_preprocess_u8(const uint8_t* u8_nhwc, int32_t N, int32_t H, int32_t W, int32_t C, const float* mean, const float* stdv,
+                                   const int32_t* aug, float post_scale, float* out_nchw, nunet_stream_t s) {
+  NUNET_REQUIRE(u8_nhwc && out_nchw && N > 0 && H > 0 && W > 0 && C > 0, "preprocess_u8: bad args");
+  const int64_t total = (int64_t)N * C * H * W;
+  hipStream_t st = (hipStream_t)s;
+  ProfScope ps(PC_LAYOUT, 0, (double)total * 5, st);
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(total, 256 * 4, 2048)), dim3(256), 0, st, u8_nhwc, N, H, W, C, mean, stdv, aug, post_scale, out_nchw);
+  return nunet_check_launch("preprocess_u8");
+}
+
+// ---------------------------------------------------------------------------
 // BatchNorm (+ReLU) (+2x2 max-pool) forward
 // ---------------------------------------------------------------------------
 struct BnFwdP {

@@ -435,3 +435,30 @@ def test_lovasz_hinge_against_reference_goldens():
         np.testing.assert_allclose(x.grad.cpu().numpy() * 2, g["dx_" + tag], atol=2e-7, rtol=2e-4, err_msg=tag)
     with pytest.raises(L.NunetError):
         crit(torch.zeros(1, 1, 256, 256, device=DEV), torch.zeros(1, 1, 256, 256, device=DEV))   # > 16384 px: refused loudly
+
+
+def test_device_input_pipeline_matches_host_pipeline(synth):
+    """uint8 HWC -> Normalize -> /255 -> CHW (+rot90/flip) on the device equals the
+    host pipeline of the reference's Dataset (dataset.py:66-74) as restated by synth.synth_images."""
+    from nunet_amd import dataset as D
+    n, h, w = 5, 32, 32
+    rng = np.random.default_rng(1234)
+    raw = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+    ref = synth.synth_images(n, h, w, 3, seed=1234)                 # same stream -> same raw bytes
+    out = D.preprocess_images(torch.from_numpy(raw).to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-7, rtol=2e-5)
+    codes = torch.tensor([0, 1, 2 | 4, 3 | 8, 4 | 8], dtype=torch.int32, device=DEV)
+    aug = D.preprocess_images(torch.from_numpy(raw).to(DEV), codes).cpu().numpy()
+    for i, cde in enumerate(codes.tolist()):
+        e = np.rot90(ref[i], k=cde & 3, axes=(1, 2))
+        if cde & 4:
+            e = e[:, :, ::-1]
+        if cde & 8:
+            e = e[:, ::-1, :]
+        np.testing.assert_allclose(aug[i], e, atol=2e-7, rtol=2e-5, err_msg=str(cde))
+    m8 = (rng.random((n, h, w, 2)) > 0.5).astype(np.uint8) * 255
+    mk = D.preprocess_masks(torch.from_numpy(m8).to(DEV), codes).cpu().numpy()
+    assert set(np.unique(mk)) <= {0.0, 1.0}
+    e = np.rot90((m8[1] / 255.0).transpose(2, 0, 1), k=1, axes=(1, 2))
+    np.testing.assert_array_equal(mk[1], e.astype(np.float32))
+    assert D.draw_augmentation(8).dtype == torch.int32
