@@ -134,13 +134,13 @@ def main():
     value = world * n * args.steps / dt
 
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline and rank == 0 and world == 1:     # single-process leg: no collectives inside
         # live per-kernel timing: the same step, eager, hipEvents around every launch on its launch
         # stream; single-lane issue for this pass so that kernels are timed alone (the timed region
         # above runs the lanes concurrently)
         L.check(L.lib().nunet_plan_set_multistream(ts.pl.handle, 0), "set_multistream")
         for _ in range(2):
-            ts._fwd_bwd(); ts._allreduce(); ts._opt()
+            ts._fwd_bwd(); ts._opt()
         torch.cuda.synchronize()
         reps = max(3, min(10, args.steps))
         L.profile_begin()

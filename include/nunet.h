@@ -243,6 +243,16 @@ int nunet_plan_forward(nunet_plan* p, const float* params, float* bnbuf, int64_t
 /* grads: flat fp32 in params order. accumulate: += instead of assign. */
 int nunet_plan_backward(nunet_plan* p, const float* params, const float* dlogits, void* arena,
                         float* grads, int32_t accumulate, nunet_stream_t s);
+/* Backward in phases, for overlapping the data-parallel gradient exchange with the rest of backward:
+ * phases bit 0 = clear scratch + heads + the last anti-diagonal's blocks (75 % of the gradient bytes),
+ * bit 1 = the remaining blocks, bit 2 = unpack into `grads`. nunet_plan_backward == phases 7.
+ * The native-layout fp32 gradient scratch lives in the arena at *byte_offset, in gradient-ready order:
+ * its first *bucket0_floats floats are final after phase 1, all *total_floats after phase 2; a
+ * data-parallel caller all-reduces those two ranges (sum) and then runs phase 4. */
+int nunet_plan_backward_phase(nunet_plan* p, const float* params, const float* dlogits, void* arena,
+                              float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s);
+int nunet_plan_grad_scratch(const nunet_plan* p, int64_t* byte_offset, int64_t* bucket0_floats,
+                            int64_t* total_floats);
 /* Multi-lane issue (default on; env NUNET_MULTISTREAM=0 disables): the plan forks onto
  * its own streams (one per pyramid level + one per level for weight gradients), with event
  * dependencies per buffer, and re-joins `s` before returning control - all work is ordered

@@ -182,7 +182,8 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   bool lanes_external;
   std::vector<hipStream_t> cap_streams;   // never-reused streams for capture-time lane continuation
   size_t cap_next;
-  void* gs_clean_arena;   // arena whose gradient scratch was cleared by the last training forward
+  void* gs_clean_arena;
+  bool bwd_written[5][5]; int bwd_pp[5];   // state carried between backward phases   // arena whose gradient scratch was cleared by the last training forward
 };
 struct nunet_plan;
 static PlanRt* rt_of(nunet_plan* P);
@@ -195,6 +196,7 @@ struct nunet_plan {
   std::vector<int> reg;         // registration (parameter) order -> index into exec
   std::vector<Head> heads;
   long long nparams, nbnbuf; int nbn;
+  int first_phase_nodes; long long gs_bucket0;   // backward phase 1 = heads + this many last nodes; its gradient-scratch prefix
   // arena regions (byte offsets)
   size_t off_stats, stats_floats;
   size_t off_gs, gs_floats;     // grad scratch + bn-bwd sums (zeroed every backward)
@@ -270,7 +272,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     c.rm_off = bo; bo += cout; c.rv_off = bo; bo += cout; c.bn_index = bn++;
     c.wf = wp; wp += 9LL * cout * c.cinpad; wp = (wp + 127) / 128 * 128;
     if (need_wd) { c.wd = wp; wp += 9LL * cout * cin; wp = (wp + 127) / 128 * 128; } else c.wd = -1;
-    c.gs = gs; gs += 9LL * cout * c.cinpad + 3LL * cout;
+    c.gs = -1;   // assigned below, in gradient-ready order
     c.stats = sv; c.save = sv; c.bsum = sv; sv += 2LL * cout;
   };
   for (size_t r = 0; r < P->reg.size(); ++r) {
@@ -287,9 +289,25 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     Head h;
     h.w_off = po; po += (long long)cfg->num_classes * NBF[0];
     h.b_off = po; po += cfg->num_classes;
-    h.gs = gs; gs += (long long)HEAD_SLABS * ((long long)cfg->num_classes * NBF[0] + cfg->num_classes);
+    h.gs = -1;
     h.slot = unet ? 1 : (nheads == 4 ? k + 1 : 4);
     P->heads.push_back(h);
+  }
+  // Gradient scratch in the order gradients COMPLETE during backward (heads, then blocks in reverse
+  // execution order): the first bucket = heads + the last anti-diagonal (75 % of the bytes,
+  // SURVEY.md §3.4) is a contiguous prefix, ready for an early all-reduce.
+  for (size_t k = 0; k < P->heads.size(); ++k) {
+    P->heads[k].gs = gs; gs += (long long)HEAD_SLABS * ((long long)cfg->num_classes * NBF[0] + cfg->num_classes);
+  }
+  P->first_phase_nodes = unet ? 4 : 5;
+  P->gs_bucket0 = 0;
+  for (int k = (int)P->exec.size() - 1; k >= 0; --k) {
+    Node& n = P->exec[k];
+    for (int cv = 1; cv >= 0; --cv) {
+      ConvL& c = cv ? n.c2 : n.c1;
+      c.gs = gs; gs += 9LL * c.cout * c.cinpad + 3LL * c.cout;
+    }
+    if (k == (int)P->exec.size() - P->first_phase_nodes) P->gs_bucket0 = gs;
   }
   P->nparams = po; P->nbnbuf = bo; P->nbn = bn;
   P->wpack_elems = wp;
@@ -708,7 +726,22 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   return rc;
 }
 
+extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s);
 extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, nunet_stream_t s) {
+  return nunet_plan_backward_phase(P, params, dlogits, arena, grads, accumulate, 7, s);
+}
+
+extern "C" int nunet_plan_grad_scratch(const nunet_plan* P, int64_t* byte_offset, int64_t* bucket0_floats, int64_t* total_floats) {
+  NUNET_REQUIRE(P && byte_offset && bucket0_floats && total_floats, "plan_grad_scratch: null pointer");
+  *byte_offset = (int64_t)P->off_gs;
+  *bucket0_floats = P->gs_bucket0;
+  *total_floats = (int64_t)(P->gs_floats - P->stats_floats);
+  return NUNET_OK;
+}
+
+// phases: 1 = clear scratch, heads and the last anti-diagonal's blocks (75 % of the gradient bytes);
+//         2 = the remaining blocks; 4 = unpack into the flat OIHW gradient arena. 7 = everything.
+extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s) {
   NUNET_REQUIRE(P && params && dlogits && arena && grads, "plan_backward: null pointer");
   hipStream_t st = (hipStream_t)s;
   const nunet_plan_cfg& c = P->cfg;
@@ -717,15 +750,23 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
   float* bsums = gsr + (P->gs_floats - P->stats_floats);
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
-  if (rt_of(P)->gs_clean_arena == arena) rt_of(P)->gs_clean_arena = nullptr;   // cleared by the forward that produced the activations
-  else CK(nunet_zero_async(gsr, P->gs_floats * 4, st));
-  bool written[5][5]; memset(written, 0, sizeof(written));
-  int pp[5] = {0, 0, 0, 0, 0};   // per-level ping-pong of the dY scratch
+  bool (&written)[5][5] = rt_of(P)->bwd_written;
+  int (&pp)[5] = rt_of(P)->bwd_pp;   // per-level ping-pong of the dY scratch
+  if (phases & 1) {
+    if (rt_of(P)->gs_clean_arena == arena) rt_of(P)->gs_clean_arena = nullptr;   // cleared by the forward that produced the activations
+    else CK(nunet_zero_async(gsr, P->gs_floats * 4, st));
+    memset(written, 0, sizeof(written));
+    memset(pp, 0, sizeof(pp));
+  }
+  const int nnodes = (int)P->exec.size();
+  const int k_split = nnodes - P->first_phase_nodes;      // phase 1: nodes [k_split, nnodes); phase 2: [0, k_split)
+  const int k_hi = (phases & 1) ? nnodes - 1 : k_split - 1;
+  const int k_lo = (phases & 2) ? 0 : k_split;
 
   Sched S; S.init(P, st, 1);
   int rc = NUNET_OK;
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
-  for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK; ++k) {
+  for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK && (phases & 1); ++k) {
     const Head& h = P->heads[k];
     hipStream_t ls = S.begin(0, {R_X + h.slot, R_DLOGITS}, {R_GX + h.slot, R_GSV + 30 + (int)k});
     rc = nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
@@ -735,7 +776,7 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
     written[0][h.slot] = true;
   }
 
-  for (int k = (int)P->exec.size() - 1; k >= 0 && rc == NUNET_OK; --k) {
+  for (int k = k_hi; k >= k_lo && rc == NUNET_OK; --k) {
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
     const int lane = lane_of(P, n), wlane = 5 + lane, rb = R_BLK + k * B_STRIDE, rl = R_LVL + k * L_STRIDE;
@@ -834,6 +875,7 @@ extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const flo
   S.join();
   if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_backward: capture lane pool exhausted"); rc = NUNET_EINVAL; }
   if (rc) return rc;
+  if (!(phases & 4)) return NUNET_OK;
   P->utab.accumulate = accumulate;
   int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
   if (gx > 512) gx = 512;

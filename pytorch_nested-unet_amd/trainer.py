@@ -47,27 +47,72 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         self.use_graph = use_graph
         self.g_fb = None
+        self.g_b2 = None
         self.g_opt = None
+        self._buckets = self._grad_scratch() if self.world > 1 else None
         for p, off in zip(self.eng.module_params, self.eng.param_off):
             p.grad = self.eng.flat_grads[off:off + p.numel()].view(p.shape)
 
     # -- pieces -------------------------------------------------------------------
-    def _fwd_bwd(self):
+    def _fwd_loss(self):
         lib, eng, pl = L.lib(), self.eng, self.pl
         st = L.stream()
         L.check(lib.nunet_plan_forward(pl.handle, L.ptr(eng.flat_params), L.ptr(eng.bnbuf), L.ptr(eng.nbt),
                                        L.ptr(self.x), L.ptr(pl.arena), L.ptr(self.logits), 1, st), "plan_forward")
         L.check(lib.nunet_loss_step(L.ptr(self.logits), L.ptr(self.t), self.n, self.per, self.heads, L.ptr(self.loss_ws),
                                     L.ptr(self.dlogits), L.ptr(self.loss_out), L.ptr(self.meters), st), "loss_step")
-        L.check(lib.nunet_plan_backward(pl.handle, L.ptr(eng.flat_params), L.ptr(self.dlogits), L.ptr(pl.arena),
-                                        L.ptr(eng.flat_grads), 0, st), "plan_backward")
         pl.trained_forward = True
+
+    def _bwd(self, phases):
+        eng, pl = self.eng, self.pl
+        L.check(L.lib().nunet_plan_backward_phase(pl.handle, L.ptr(eng.flat_params), L.ptr(self.dlogits), L.ptr(pl.arena),
+                                                  L.ptr(eng.flat_grads), 0, phases, L.stream()), "plan_backward_phase")
+
+    def _fwd_bwd(self):
+        self._fwd_loss()
+        self._bwd(7)
 
     def _opt(self):
         eng = self.eng
         L.check(L.lib().nunet_sgd_step(L.ptr(eng.flat_params), L.ptr(eng.flat_grads), L.ptr(self.mom),
                                        eng.flat_params.numel(), L.ptr(self.lr), self.momentum, self.wd,
                                        1 if self.nesterov else 0, 0, 1.0 / self.world, L.stream()), "sgd_step")
+
+    def _grad_scratch(self):
+        """The plan's native-layout gradient scratch as two fp32 views in gradient-ready order."""
+        import ctypes as C
+        off, b0, tot = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().nunet_plan_grad_scratch(self.pl.handle, C.byref(off), C.byref(b0), C.byref(tot)), "plan_grad_scratch")
+        flat = self.pl.arena[off.value:off.value + 4 * tot.value].view(torch.float32)
+        return flat[:b0.value], flat[b0.value:]
+
+    def _exchange(self, t):
+        """Sum a gradient bucket over ranks; asynchronous under RCCL so that it overlaps what follows."""
+        if dist.get_backend(self.pg) == "gloo":
+            allreduce_flat_(t, self.pg)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _dp_step(self, run1, run2, run3):
+        """Data-parallel step: bucket 0 (heads + the last anti-diagonal = 75 % of the gradient bytes,
+        complete after backward phase 1) is all-reduced while phase 2 runs; bucket 1 follows; unpack +
+        SGD (grad_scale 1/world) run on the reduced scratch."""
+        b0, b1 = self._buckets
+        run1()
+        h0 = self._exchange(b0)
+        run2()
+        h1 = self._exchange(b1)
+        for h in (h0, h1):
+            if h is not None:
+                h.wait()
+        run3()
+
+    def _eager_step(self):
+        if self.world > 1:
+            self._dp_step(lambda: (self._fwd_loss(), self._bwd(1)), lambda: self._bwd(2), lambda: (self._bwd(4), self._opt()))
+        else:
+            self._fwd_bwd()
+            self._opt()
 
     def _allreduce(self):
         if self.world > 1:
@@ -89,19 +134,25 @@ class TrainStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                self._fwd_bwd()
-                self._allreduce()
-                self._opt()
+                self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            self._fwd_bwd()
-            if self.world == 1:
+        if self.world == 1:
+            self.g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fb):
+                self._fwd_bwd()
                 self._opt()
-        if self.world > 1:
-            self.g_opt = torch.cuda.CUDAGraph()
+        else:
+            self.g_fb = torch.cuda.CUDAGraph()          # forward + loss + backward phase 1
+            with torch.cuda.graph(self.g_fb):
+                self._fwd_loss()
+                self._bwd(1)
+            self.g_b2 = torch.cuda.CUDAGraph()          # backward phase 2
+            with torch.cuda.graph(self.g_b2):
+                self._bwd(2)
+            self.g_opt = torch.cuda.CUDAGraph()         # unpack + SGD
             with torch.cuda.graph(self.g_opt):
+                self._bwd(4)
                 self._opt()
         torch.cuda.synchronize()
         with torch.no_grad():
@@ -116,14 +167,12 @@ class TrainStep:
             self.x.copy_(inp, non_blocking=True)
             self.t.copy_(target, non_blocking=True)
         if self.g_fb is not None:
-            self.g_fb.replay()
             if self.world > 1:
-                self._allreduce()
-                self.g_opt.replay()
+                self._dp_step(self.g_fb.replay, self.g_b2.replay, self.g_opt.replay)
+            else:
+                self.g_fb.replay()
         else:
-            self._fwd_bwd()
-            self._allreduce()
-            self._opt()
+            self._eager_step()
         self.steps += 1
 
     def set_lr(self, lr):
