@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnunet.so")
+LIB_PATH = os.environ.get("NUNET_LIB_PATH") or os.path.join(_HERE, "libnunet.so")   # override: diagnostic builds only
 
 F32, BF16, F16 = 0, 1, 2
 DTYPES = {"fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F16, "float16": F16,
@@ -114,6 +114,14 @@ _SIG = {
     "nunet_plan_set_lanes": (_i32, [_vp, C.POINTER(_vp), _i32]),
     "nunet_profile_begin": (_i32, []),
     "nunet_profile_end": (_i32, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
+    "nunet_debug_spin": (_i32, [_i32, _i32, _vp]),
+    "nunet_graph_begin": (_i32, [_vp]),
+    "nunet_graph_end": (_i32, [_vp, C.POINTER(_vp)]),
+    "nunet_graph_launch": (_i32, [_vp, _vp]),
+    "nunet_graph_tune": (_i32, [_vp, _i32, _i32, _u32, C.POINTER(_f32), C.POINTER(_f32)]),
+    "nunet_graph_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "nunet_graph_destroy": (None, [_vp]),
+    "nunet_plan_stamps_read": (_i32, [_vp, _i32, C.POINTER(C.c_uint64), _i32, C.POINTER(_i32), C.c_char_p, _i32]),
 }
 
 _lib = None

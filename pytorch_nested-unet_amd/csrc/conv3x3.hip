@@ -58,6 +58,22 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 // ---------------------------------------------------------------------------
 // forward / dgrad kernel
 // ---------------------------------------------------------------------------
+// Tile-space -> global pixel (or -1 = zero padding / masked row).
+// Regular tiling: (n, y, x) inside image n. Stacked-rows tiling (SH = H + 1): the batch is ONE virtual
+// image of N * SH rows, virtual row v = n * SH + y + 1, rows with v % SH == 0 are zero separators that
+// serve as bottom halo of image n - 1 and top halo of image n. Tiles are TH virtual rows x full width,
+// so small images (12 x 12 at level 3 of a 96 x 96 input) fill a 128-pixel tile to 86 % instead of 56 %.
+__device__ __forceinline__ int map_pixel(int n, int y, int x, int N, int H, int W, int SH) {
+  if (SH) {
+    if (y < 0 || x < 0 || x >= W) return -1;
+    const int n2 = y / SH, yy = y - n2 * SH - 1;
+    if (n2 >= N || yy < 0) return -1;
+    return (n2 * H + yy) * W + x;
+  }
+  if (n < N && y >= 0 && y < H && x >= 0 && x < W) return (n * H + y) * W + x;
+  return -1;
+}
+
 struct ConvP {
   const void* src0; const void* src1;
   int C0, C1, P0, P1;
@@ -68,6 +84,7 @@ struct ConvP {
   float* stats;
   int N, H, W, Cin, Cout;
   int NI, TH, TW, tilesX, tilesY, tilesG, nCoT, nItems;
+  int SH;                // stacked-rows tiling: H + 1 (0 = off), see map_pixel
   int S, nch0, nch;      // K-split: slices, channel chunks of source 0 / total (SK kernels only)
   float* slabs;          // [S][pixels][Cout] fp32 partial sums
   long long slab_stride; // pixels * Cout
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       int gp = -1;
       if (hcode[k] >= 0) {
         const int n = it.n0 + (hcode[k] >> 20), y = it.y0 + ((hcode[k] >> 10) & 1023) - 1, x = it.x0 + (hcode[k] & 1023) - 1;
-        if (n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W) gp = (n * p.H + y) * p.W + x;
+        gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
       }
       hgp[k] = gp;
     }
@@ -181,7 +198,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   Vec16<T> hreg[C::UH];
   Vec16<T> wreg[C::UW];
   // units past the valid channels of a chunk are zero-filled, so every chunk runs KS full k-steps
+#ifdef NUNET_ABL
+  bool abl_loaded = false, abl_written = false;   // diagnostic builds (tools/build_ablations.sh) only
+#endif
   auto load_regs = [&](const Item& it, int kb, int kc) {
+#if defined(NUNET_ABL) && (NUNET_ABL & 1)
+    if (abl_loaded) return;
+    abl_loaded = true;
+#endif
     const T* src; int ch, pitch;
     if (kb < p.C0) { src = (const T*)p.src0; ch = kb; pitch = p.P0; }
     else { src = (const T*)p.src1; ch = kb - p.C0; pitch = p.P1; }
@@ -202,6 +226,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
     }
   };
   auto write_lds = [&]() {
+#if defined(NUNET_ABL) && (NUNET_ABL & 2)
+    if (abl_written) return;
+    abl_written = true;
+#endif
 #pragma unroll
     for (int k = 0; k < C::UH; ++k) {
       const int u = tid + k * NT;
@@ -246,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
         int gp = -1;
         if (code >= 0) {
           const int n = cur.n0 + (code >> 20), y = cur.y0 + ((code >> 10) & 1023), x = cur.x0 + (code & 1023);
-          if (n < p.N && y < p.H && x < p.W) gp = (n * p.H + y) * p.W + x;
+          gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
         }
         s_gpix[m] = gp;
       }
@@ -272,6 +300,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       load_regs(nxt, nkb, nkc);
     }
     // fully unrolled tap x k-step sweep; fragments of step s+1 are read while step s multiplies
+#if defined(NUNET_ABL) && (NUNET_ABL & 4)
+    if (p.N < 0)
+#endif
     {
       typename M::Frag fa[2][SM], fb[2][SN];
 #pragma unroll
@@ -351,7 +382,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
         const int m = u / SEGS, seg = u - m * SEGS;
         if (m < BM) {
           const int gp = s_gpix[m];
+#if defined(NUNET_ABL) && (NUNET_ABL & 8)
+          if (gp >= 0 && p.N < 0) {
+#else
           if (gp >= 0) {
+#endif
             const int co = cur.co0 + seg * EPV;
             T* q; bool accum;
             if (co < p.D0) {
@@ -445,9 +480,9 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
 
 
 // tile-geometry chooser shared by fwd and wgrad
-struct TileGeom { int NI, TH, TW, tilesX, tilesY, tilesG; };
+struct TileGeom { int NI, TH, TW, tilesX, tilesY, tilesG, SH; };
 TileGeom nunet_choose_tile(int N, int H, int W, int BM, int HPMAX) {
-  TileGeom best{1, 1, 1, W, H, N};
+  TileGeom best{1, 1, 1, W, H, N, 0};
   double best_score = -1.0;
   for (int tw = 1; tw <= W && tw <= BM; ++tw) {
     for (int th = 1; th <= H && th * tw <= BM; ++th) {
@@ -461,9 +496,25 @@ TileGeom nunet_choose_tile(int N, int H, int W, int BM, int HPMAX) {
         const double halo = (double)hp / ((double)ni * th * tw);
         // prefer utilisation, then low halo overhead, then wide rows (coalescing)
         const double score = util * 1000.0 - halo * 10.0 + (tw >= 16 ? 1.0 : 0.0);
-        if (score > best_score) { best_score = score; best = TileGeom{ni, th, tw, tX, tY, tG}; }
+        if (score > best_score) { best_score = score; best = TileGeom{ni, th, tw, tX, tY, tG, 0}; }
       }
     }
+  }
+  // stacked-rows candidates (map_pixel): TH virtual rows x full width over N * (H + 1) virtual rows;
+  // taken only when they beat the best regular tiling by a clear margin (they waste the separator rows)
+  static int stacked = -1;
+  if (stacked < 0) { const char* e = getenv("NUNET_STACKED_TILES"); stacked = e ? atoi(e) : 1; }
+  if (stacked && W <= BM && (long)N * (H + 1) < (1 << 20)) {
+    const double best_util = (double)N * H * W / ((double)best.tilesX * best.tilesY * best.tilesG * BM);
+    const int VH = N * (H + 1);
+    double su = 0.0; int sth = 0;
+    for (int th = 1; th * W <= BM && th < 1000; ++th) {
+      if ((long)(th + 2) * (W + 2) > HPMAX) break;
+      const int tY = ceil_div(VH, th);
+      const double util = (double)N * H * W / ((double)tY * BM);
+      if (util > su) { su = util; sth = th; }
+    }
+    if (sth > 0 && su > best_util * 1.08) best = TileGeom{1, sth, W, 1, ceil_div(VH, sth), 1, H + 1};
   }
   return best;
 }
@@ -479,7 +530,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.stats = d->stats;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1; p.Cout = d->D0 + d->D1;
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
-  p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG;
+  p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
   p.nCoT = p.Cout / C::BN;
   long items = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
   // K-split for the grid-starved deep levels: slices of the channel-chunk loop become extra items, each
@@ -487,7 +538,9 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.S = 1; p.slabs = nullptr; p.slab_stride = 0;
   p.nch0 = ceil_div(p.C0, C::KC);
   p.nch = p.nch0 + (p.C1 > 0 ? ceil_div(p.C1, C::KC) : 0);
-  if (d->splitk_ws && items <= 100 && p.nch >= 8 && p.Cout <= 1024) {
+  static int sk_max_items = -1;
+  if (sk_max_items < 0) { const char* e = getenv("NUNET_SK_MAXITEMS"); sk_max_items = e ? atoi(e) : 100; }
+  if (d->splitk_ws && items <= sk_max_items && p.nch >= 8 && p.Cout <= 1024) {
     int S = (int)((320 + items - 1) / items);
     if (S > p.nch / 2) S = p.nch / 2;
     const long long need = (long long)S * d->N * d->H * d->W * p.Cout;
@@ -573,6 +626,7 @@ struct WgP {
   int N, H, W, Cin;
   int NI, TH, TW, tilesX, tilesY, tilesG;
   int nCoT, nCiT, ksplit, nMT;
+  int SH;
 };
 
 template <typename T> struct WgCfg {
@@ -670,7 +724,8 @@ __global__ __launch_bounds__(192) void wgrad_kernel(WgP p) {
       dreg[k] = zero16<T>();
       if (dcode[k] >= 0) {
         const int n = n0 + (dcode[k] >> 20), y = y0 + ((dcode[k] >> 10) & 1023), x = x0 + (dcode[k] & 1023);
-        if (n < p.N && y < p.H && x < p.W) dreg[k] = ld16(dsrc + ((size_t)(n * p.H + y) * p.W + x) * p.PY);
+        const int gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
+        if (gp >= 0) dreg[k] = ld16(dsrc + (size_t)gp * p.PY);
       }
     }
 #pragma unroll
@@ -678,8 +733,8 @@ __global__ __launch_bounds__(192) void wgrad_kernel(WgP p) {
       areg[k] = zero16<T>();
       if (acode[k] >= 0 && cvalid) {
         const int n = n0 + (acode[k] >> 20), y = y0 + ((acode[k] >> 10) & 1023) - 1, x = x0 + (acode[k] & 1023) - 1;
-        if (n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W)
-          areg[k] = ld16(asrc + ((size_t)(n * p.H + y) * p.W + x) * apitch + ach);
+        const int gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
+        if (gp >= 0) areg[k] = ld16(asrc + (size_t)gp * apitch + ach);
       }
     }
   };
@@ -772,7 +827,7 @@ template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStre
   p.dy = d->dy; p.Cout = d->Cout; p.PY = d->PY; p.dw = d->dw;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1;
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
-  p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG;
+  p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
   p.nCoT = ceil_div(p.Cout, 32);
   p.nCiT = ceil_div(p.Cin, 32);
   p.nMT = g.tilesX * g.tilesY * g.tilesG;

@@ -10,8 +10,11 @@
 #include <string.h>
 
 #include <initializer_list>
+#include <functional>
 
 #include <vector>
+#include <string>
+#include <stdarg.h>
 
 #include "common.h"
 
@@ -184,7 +187,14 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   size_t cap_next;
   void* gs_clean_arena;
   bool bwd_written[5][5]; int bwd_pp[5];   // state carried between backward phases   // arena whose gradient scratch was cleared by the last training forward
+  // NUNET_STAMPS=1 diagnostic: a 1-thread kernel after every scheduled op writes the 100 MHz wall clock,
+  // so the real timeline of an (unprofiled) hipGraph replay can be read back (tools/stamp_timeline.py)
+  unsigned long long* stamps;              // device, [2][STAMP_CAP]
+  std::vector<std::string> stamp_labels[2];
 };
+void graph_tag_tail(hipStream_t st, int lane);   // graph.hip: lane bookkeeping of an active nunet_graph capture
+#define STAMP_CAP 512
+__global__ void stamp_kernel(unsigned long long* p) { *p = wall_clock64(); }
 struct nunet_plan;
 static PlanRt* rt_of(nunet_plan* P);
 struct nunet_plan {
@@ -384,6 +394,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->lanes_external = false;
   rt->cap_next = 0;
   rt->gs_clean_arena = nullptr;
+  rt->stamps = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
   { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
   for (int l = 0; l < NLANES; ++l) {
@@ -405,6 +416,7 @@ extern "C" void nunet_plan_destroy(nunet_plan* p) {
     for (size_t k = 0; k < p->rt->cap_streams.size(); ++k) (void)hipStreamDestroy(p->rt->cap_streams[k]);
     for (int q = 0; q < 2; ++q)
       for (size_t k = 0; k < p->rt->events[q].size(); ++k) (void)hipEventDestroy(p->rt->events[q][k]);
+    if (p->rt->stamps) (void)hipFree(p->rt->stamps);
     delete p->rt;
   }
   delete p;
@@ -462,6 +474,19 @@ struct Sched {
   hipEvent_t fork_ev;
   hipEvent_t pend[64]; int npend;
   int lane_map[NLANES];
+  int pass;
+  char cur_name[32];
+  void name(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(cur_name, sizeof(cur_name), fmt, ap); va_end(ap);
+  }
+  void stamp(hipStream_t st, int lane) {
+    if (!rt->stamps) return;
+    std::vector<std::string>& lab = rt->stamp_labels[pass];
+    if ((int)lab.size() >= STAMP_CAP) return;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, rt->stamps + (size_t)pass * STAMP_CAP + lab.size());
+    char b[48]; snprintf(b, sizeof(b), "L%d %s", lane, cur_name);
+    lab.push_back(b);
+  }
 
   hipEvent_t new_event() {
     if (*pool_used == pool->size()) {
@@ -489,18 +514,23 @@ struct Sched {
   }
   // begin an op on `lane` reading `rd` and writing `wr` resources; returns the stream to launch on
   hipStream_t begin(int lane, std::initializer_list<int> rd, std::initializer_list<int> wr) {
+    int r[16], w[16], nr = 0, nw = 0;
+    for (int x : rd) if (x >= 0 && nr < 16) r[nr++] = x;
+    for (int x : wr) if (x >= 0 && nw < 16) w[nw++] = x;
+    return begin_v(lane_map[lane], r, nr, w, nw);
+  }
+  hipStream_t begin_v(int lane, const int* rd, int nrd, const int* wr, int nwr) {   // `lane` already mapped
     if (!multi) return main_s;
-    lane = lane_map[lane];
     cur_lane = lane; nreads = 0; nwrites = 0; npend = 0;
     hipStream_t st = lane_s[lane];      // may be null while capturing (lane not started yet)
-    for (int r : rd) {
-      if (r < 0) continue;
+    for (int q = 0; q < nrd; ++q) {
+      const int r = rd[q];
       reads[nreads++] = r;
       Res& R = res[r];
       want(R.w_ev, R.w_st, st);
     }
-    for (int w : wr) {
-      if (w < 0) continue;
+    for (int q = 0; q < nwr; ++q) {
+      const int w = wr[q];
       writes[nwrites++] = w;
       Res& R = res[w];
       want(R.w_ev, R.w_st, st);
@@ -521,10 +551,33 @@ struct Sched {
     for (int k = 0; k < npend; ++k) (void)hipStreamWaitEvent(st, pend[k], 0);
     return st;
   }
+
+  // ---- deferred ops + list scheduling ------------------------------------------------------
+  // ROCm resolves a cross-queue dependency of a graph node against what has ALREADY been placed on
+  // the producer's queue, so the order in which ops are issued (captured) decides when a side block
+  // can start: issuing the x_{i,j} grid block by block left three lanes idle for the first third of
+  // the backward pass (profiles/r01_summary.md). Ops are therefore collected first, then issued in
+  // the order of a simulated list schedule (earliest start, longest remaining path first). `leaf`
+  // ops (weight gradients: nothing but the final unpack consumes them) float to whichever lane is
+  // idle. Conflicting ops (RAW/WAW/WAR on a resource) keep their program order, so the events
+  // derived at issue time are the ones program order would give.
+  struct Op { int lane, leaf; float cost; int nrd, nwr; int rd[8], wr[8]; char name[32]; std::function<int(hipStream_t)> fn; };
+  std::vector<Op> ops;
+  void add(int lane, int leaf, float cost, std::initializer_list<int> rd, std::initializer_list<int> wr, std::function<int(hipStream_t)> fn) {
+    Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0;
+    for (int x : rd) if (x >= 0 && o.nrd < 8) o.rd[o.nrd++] = x;
+    for (int x : wr) if (x >= 0 && o.nwr < 8) o.wr[o.nwr++] = x;
+    memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
+    o.fn = std::move(fn);
+    ops.push_back(std::move(o));
+  }
+  int run_ops();
   void end() {
-    if (!multi) return;
+    if (!multi) { stamp(main_s, 0); cur_name[0] = 0; return; }
     hipStream_t st = lane_s[cur_lane];
     if (!st) return;
+    stamp(st, cur_lane); cur_name[0] = 0;
+    if (capturing) graph_tag_tail(st, cur_lane);
     hipEvent_t ev = new_event();
     (void)hipEventRecord(ev, st);
     lane_tail[cur_lane] = ev;
@@ -542,9 +595,23 @@ struct Sched {
   }
 };
 
-void Sched::init(nunet_plan* P, hipStream_t s, int pass) {
+void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
+  const int pass = pass_;
+  this->pass = pass_;
+  cur_name[0] = 0;
   rt = rt_of(P);
   main_s = s;
+  {
+    static int want_stamps = -1;
+    if (want_stamps < 0) { const char* e = getenv("NUNET_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+    hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cs0);
+    if (want_stamps && !rt->stamps && cs0 != hipStreamCaptureStatusActive) {
+      if (hipMalloc((void**)&rt->stamps, 2 * STAMP_CAP * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); rt->stamps = nullptr; }
+    }
+    rt->stamp_labels[pass].clear();
+    if (rt->stamps) { snprintf(cur_name, sizeof(cur_name), "start"); stamp(s, 0); cur_name[0] = 0; }
+  }
   multi = rt->multistream != 0 && rt->lanes_ok;
   failed = false;
   capturing = false;
@@ -581,7 +648,102 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass) {
   if (multi) {
     fork_ev = new_event();
     (void)hipEventRecord(fork_ev, main_s);
+    if (capturing) graph_tag_tail(main_s, -1);   // launches made so far on the caller's stream are not ours to place
   }
+}
+
+int Sched::run_ops() {
+  const int n = (int)ops.size();
+  int rc = NUNET_OK;
+  static int listsched = -1;
+  if (listsched < 0) { const char* e = getenv("NUNET_LISTSCHED"); listsched = e ? atoi(e) : 0; }
+  std::vector<int> order; order.reserve(n);
+  std::vector<int> on_lane(n);
+  for (int j = 0; j < n; ++j) on_lane[j] = ops[j].lane;
+  if (!multi || !listsched || n < 3) {
+    for (int j = 0; j < n; ++j) order.push_back(j);
+  } else {
+    // dependency edges from program order
+    std::vector<std::vector<int>> deps(n), succ(n);
+    {
+      std::vector<int> lastw(NRES, -1);
+      std::vector<std::vector<int>> rds(NRES);
+      for (int j = 0; j < n; ++j) {
+        auto dep = [&](int d) { if (d >= 0 && d != j) { for (int x : deps[j]) if (x == d) return; deps[j].push_back(d); succ[d].push_back(j); } };
+        for (int q = 0; q < ops[j].nrd; ++q) dep(lastw[ops[j].rd[q]]);
+        for (int q = 0; q < ops[j].nwr; ++q) { const int r = ops[j].wr[q]; dep(lastw[r]); for (int x : rds[r]) dep(x); }
+        for (int q = 0; q < ops[j].nrd; ++q) rds[ops[j].rd[q]].push_back(j);
+        for (int q = 0; q < ops[j].nwr; ++q) { const int r = ops[j].wr[q]; lastw[r] = j; rds[r].clear(); }
+      }
+    }
+    std::vector<float> bl(n, 0.f);   // longest path to a sink, own cost included
+    for (int j = n - 1; j >= 0; --j) { float m = 0.f; for (int x : succ[j]) m = bl[x] > m ? bl[x] : m; bl[j] = ops[j].cost + m; }
+    int nl = 4;
+    for (int j = 0; j < n; ++j) if (ops[j].lane + 1 > nl) nl = ops[j].lane + 1;
+    if (nl > NLANES) nl = NLANES;
+    const float XL = 6.f;            // dispatch latency of an edge that crosses hardware queues (us)
+    std::vector<float> fin(n, 0.f), lane_free(nl, 0.f);
+    std::vector<char> done(n, 0);
+    std::vector<int> ndep(n);
+    int nonleaf_left = 0;
+    for (int j = 0; j < n; ++j) { ndep[j] = (int)deps[j].size(); if (!ops[j].leaf) ++nonleaf_left; }
+    auto ready_at = [&](int j, int L) { float r = 0.f; for (int d : deps[j]) { float f = fin[d] + (on_lane[d] != L ? XL : 0.f); r = f > r ? f : r; } return r; };
+    float t = 0.f;
+    int left = n;
+    while (left > 0) {
+      bool progress = false;
+      for (int L = 0; L < nl; ++L) {
+        if (lane_free[L] > t) continue;
+        int best = -1; bool best_leaf = true; float best_bl = -1.f;
+        for (int j = 0; j < n; ++j) {
+          if (done[j] || ndep[j] > 0) continue;
+          const bool leaf = ops[j].leaf != 0;
+          if (!leaf && ops[j].lane != L) continue;
+          if (leaf && L == 0 && nonleaf_left > 0) continue;          // keep the critical-chain lane free
+          if (ready_at(j, L) > t) continue;
+          if (best < 0 || (best_leaf && !leaf) || (best_leaf == leaf && bl[j] > best_bl)) { best = j; best_leaf = leaf; best_bl = bl[j]; }
+        }
+        if (best >= 0 && best_leaf) {
+          // do not start a long leaf just before an op of this lane becomes ready
+          for (int j = 0; j < n && best >= 0; ++j)
+            if (!done[j] && ndep[j] == 0 && !ops[j].leaf && ops[j].lane == L && ready_at(j, L) < t + 0.5f * ops[best].cost) best = -1;
+        }
+        if (best < 0) continue;
+        done[best] = 1; --left; if (!ops[best].leaf) --nonleaf_left;
+        on_lane[best] = L; fin[best] = t + ops[best].cost; lane_free[L] = fin[best];
+        for (int x : succ[best]) --ndep[x];
+        order.push_back(best);
+        progress = true;
+      }
+      if (progress) continue;
+      float nt = 1e30f;
+      for (int L = 0; L < nl; ++L) if (lane_free[L] > t && lane_free[L] < nt) nt = lane_free[L];
+      for (int j = 0; j < n; ++j) {
+        if (done[j] || ndep[j] > 0) continue;
+        for (int L = 0; L < nl; ++L) {
+          if (!ops[j].leaf && ops[j].lane != L) continue;
+          float r = ready_at(j, L); if (r < lane_free[L]) r = lane_free[L];
+          if (r > t && r < nt) nt = r;
+        }
+      }
+      if (nt > 1e29f) nt = t + 1.f;     // cannot happen for a valid program order; keeps the loop finite
+      t = nt;
+      if (t > 1e7f) break;
+    }
+    if (left > 0) { order.clear(); for (int j = 0; j < n; ++j) { order.push_back(j); on_lane[j] = ops[j].lane; } }
+    if (getenv("NUNET_SCHED_DUMP")) {
+      for (int j : order) fprintf(stderr, "sched %3d lane %d leaf %d cost %6.1f start %8.1f bl %7.1f\n", j, on_lane[j], ops[j].leaf, ops[j].cost, fin[j] - ops[j].cost, bl[j]);
+    }
+  }
+  for (int q = 0; q < n && rc == NUNET_OK; ++q) {
+    Op& o = ops[order[q]];
+    hipStream_t st = begin_v(on_lane[order[q]], o.rd, o.nrd, o.wr, o.nwr);
+    rc = o.fn(st);
+    memcpy(cur_name, o.name, sizeof(cur_name));
+    end();
+  }
+  ops.clear();
+  return rc;
 }
 
 // Lane of a block. Crossing HW queues costs 5-10 us of dispatch latency per dependency edge, so the
@@ -628,6 +790,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   static int pack_lanes = -1, gs_fwd = -1;
   if (pack_lanes < 0) { const char* e = getenv("NUNET_PACK_LANES"); pack_lanes = e ? atoi(e) : 0; e = getenv("NUNET_GS_FWD"); gs_fwd = e ? atoi(e) : 0; }
   if (!pack_lanes) {
+    S.name("pack");
     hipStream_t ls = S.begin(0, {}, {R_WP + 0, R_WP + 1, R_WP + 2, R_WP + 3, R_WP + 4});
     if (dt == NUNET_F32) rc = launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, ls);
     else if (dt == NUNET_BF16) rc = launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
@@ -654,6 +817,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
     const int lane = lane_of(P, n), rb = R_BLK + (int)k * B_STRIDE;
     if (n.up_slot >= 0) {
+      S.name("B%d%d.upF", n.i, n.j);
       hipStream_t ls = S.begin(lane, {R_X + (i + 1) * 5 + n.up_slot}, {rb + B_UP});
       rc = nunet_upsample2x_fwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1],
                                 AB(arena, P->X[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1],
@@ -666,17 +830,19 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       nunet_conv_desc d; memset(&d, 0, sizeof(d));
       d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
       hipStream_t ls;
+      const int rskf = P->sk_floats[i] > 0 ? R_SK + i : -1;
+      S.name("B%d%d.conv%d", n.i, n.j, cv + 1);
       if (cv == 1) {
         d.src0 = AB(arena, n.a1); d.C0 = f; d.P0 = f;
-        ls = S.begin(lane, {rb + B_A1, R_WP + i}, {rb + B_Y2, rb + B_ST2, R_SK + i});
+        ls = S.begin(lane, {rb + B_A1, R_WP + i}, {rb + B_Y2, rb + B_ST2, rskf});
       } else if (n.in_prefix == 0) {
-        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG, R_WP + i}, {rb + B_Y1, rb + B_ST1, R_SK + i}); }
-        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN, R_WP + i}, {rb + B_Y1, rb + B_ST1, R_SK + i}); }
+        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}); }
+        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}); }
       } else {
         d.src0 = AB(arena, P->X[i]); d.C0 = n.in_prefix * f; d.P0 = P->PX[i];
         d.src1 = AB(arena, n.up); d.C1 = NBF[i + 1]; d.P1 = NBF[i + 1];
         ls = S.begin(lane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
-                            n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, R_WP + i}, {rb + B_Y1, rb + B_ST1, R_SK + i});
+                            n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf});
       }
       d.wpack = wpack + (size_t)L.wf * es;
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
@@ -696,6 +862,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       b.running_mean = bnbuf + L.rm_off; b.running_var = bnbuf + L.rv_off;
       b.num_batches_tracked = nbt ? nbt + L.bn_index : nullptr;
       b.save_mean_invstd = save + L.save; b.training = training; b.momentum = 0.1f; b.eps = 1e-5f;
+      S.name("B%d%d.bnF%d", n.i, n.j, cv + 1);
       if (cv == 0) {
         b.a = AB(arena, n.a1); b.PA = f;
         ls = S.begin(lane, {rb + B_Y1, rb + B_ST1}, {rb + B_A1});
@@ -715,6 +882,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   if (rc == NUNET_OK) {
     const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
     for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK; ++k) {
+      S.name("head%d.F", (int)k);
       hipStream_t ls = S.begin(0, {R_X + P->heads[k].slot}, {R_LOGITS});
       rc = nunet_head_fwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)P->heads[k].slot * NBF[0] * es), P->PX[0],
                           params + P->heads[k].w_off, params + P->heads[k].b_off, logits + plane * k, ls);
@@ -766,13 +934,21 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   Sched S; S.init(P, st, 1);
   int rc = NUNET_OK;
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
+  // cost model (us) of the simulated schedule: launch floor + algorithmic work at the rate these
+  // kernels reach on MI355X (profiles/r01_summary.md); only the relative order matters
+  const double conv_rate = dt == NUNET_F32 ? 0.09e9 : 0.55e9, wg_rate = dt == NUNET_F32 ? 0.07e9 : 0.40e9;   // FLOP per us
+  auto cost_conv = [&](int lvl, double cin, double cout) { return (float)(9.0 + (lvl >= 3 ? 8.0 : 0.0) + 18.0 * cin * cout * (double)P->px[lvl] / conv_rate); };
+  auto cost_wg = [&](int lvl, double cin, double cout) { return (float)(12.0 + 18.0 * cin * cout * (double)P->px[lvl] / wg_rate); };
+  auto cost_mem = [&](double floor_us, double bytes) { return (float)(floor_us + bytes / 4.0e6); };
   for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK && (phases & 1); ++k) {
     const Head& h = P->heads[k];
-    hipStream_t ls = S.begin(0, {R_X + h.slot, R_DLOGITS}, {R_GX + h.slot, R_GSV + 30 + (int)k});
-    rc = nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
-                        params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
-                        written[0][h.slot] ? 1 : 0, gsr + h.gs, HEAD_SLABS, ls);
-    S.end();
+    const int acc = written[0][h.slot] ? 1 : 0;
+    S.name("head%d.B", (int)k);
+    S.add(0, 0, 12.f, {R_X + h.slot, R_DLOGITS}, {R_GX + h.slot, R_GSV + 30 + (int)k}, [=](hipStream_t ls) {
+      return nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
+                            params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
+                            acc, gsr + h.gs, HEAD_SLABS, ls);
+    });
     written[0][h.slot] = true;
   }
 
@@ -780,6 +956,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
     const int lane = lane_of(P, n), wlane = 5 + lane, rb = R_BLK + k * B_STRIDE, rl = R_LVL + k * L_STRIDE;
+    const int rsk = P->sk_floats[i] > 0 ? R_SK + i : -1;
     if (!written[i][n.out_slot]) { nunet_set_error("plan_backward: internal: grad of x%d_%d never produced", n.i, n.j); rc = NUNET_EINVAL; break; }
     nunet_wgrad_desc wdesc[2]; int wrdy[2] = {-1, -1};
     for (int cv = 1; cv >= 0 && rc == NUNET_OK; --cv) {
@@ -799,13 +976,12 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       float* gl = gsr + L.gs + 9LL * L.cout * L.cinpad;
       b.dbias = gl; b.dgamma = gl + L.cout; b.dbeta = gl + 2 * L.cout;
       b.dy = dybuf; b.PDY = f;
-      hipStream_t ls = S.begin(lane, {rda, ry}, {rdy, R_GSV + cidx});
-      rc = nunet_bn_relu_bwd_reduce(&b, ls);
-      if (rc == NUNET_OK) rc = nunet_bn_relu_bwd_apply(&b, ls);
-      S.end();
-      if (rc) break;
-      // weight gradient: prepared here, issued after the block's dgrad chain (below) so that
-      // the levels waiting on this block's input gradients start earlier
+      S.name("B%d%d.bnB%d", n.i, n.j, cv + 1);
+      S.add(lane, 0, cost_mem(12.0, 5.0 * (double)P->px[i] * f * es), {rda, ry}, {rdy, R_GSV + cidx}, [=](hipStream_t ls) {
+        int r = nunet_bn_relu_bwd_reduce(&b, ls);
+        return r ? r : nunet_bn_relu_bwd_apply(&b, ls);
+      });
+      // weight gradient: a leaf of the dependency graph (only the final unpack reads it)
       nunet_wgrad_desc& w = wdesc[cv]; memset(&w, 0, sizeof(w));
       w.dtype = dt; w.N = c.N; w.H = H; w.W = W;
       if (cv == 1) { w.src0 = AB(arena, n.a1); w.C0 = f; w.P0 = f; }
@@ -824,54 +1000,58 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
       d.src0 = b.dy; d.C0 = f; d.P0 = f;
       d.wpack = wpack + (size_t)L.wd * es;
+      if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
+      S.name("B%d%d.dgrad%d", n.i, n.j, cv + 1);
       if (cv == 1) {
         d.dst0 = AB(arena, P->off_da1[k]); d.D0 = f; d.Q0 = f;
-        ls = S.begin(lane, {rdy}, {rl + L_DA1, R_SK + i});
+        S.add(lane, 0, cost_conv(i, f, f), {rdy}, {rl + L_DA1, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
       } else if (n.in_prefix == 0) {
         d.dst0 = AB(arena, P->off_gpin[k]); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1];
-        ls = S.begin(lane, {rdy}, {rl + L_GPIN, R_SK + i});
+        S.add(lane, 0, cost_conv(i, f, NBF[i - 1]) + (i >= 3 ? 12.f : 0.f), {rdy}, {rl + L_GPIN, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
       } else {
         d.dst0 = AB(arena, P->GX[i]); d.D0 = n.in_prefix * f; d.Q0 = P->PX[i]; d.acc_slot_w = f;
         for (int q = 0; q < n.in_prefix; ++q) { if (written[i][q]) d.acc0_mask |= 1u << q; written[i][q] = true; }
         d.dst1 = AB(arena, P->off_gup[k]); d.D1 = NBF[i + 1]; d.Q1 = NBF[i + 1];
-        ls = S.begin(lane, {rdy}, {R_GX + i * 5 + 0, n.in_prefix > 1 ? R_GX + i * 5 + 1 : -1, n.in_prefix > 2 ? R_GX + i * 5 + 2 : -1,
-                                   n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP, R_SK + i});
+        S.add(lane, 0, cost_conv(i, f, n.in_prefix * f + NBF[i + 1]), {rdy},
+              {R_GX + i * 5 + 0, n.in_prefix > 1 ? R_GX + i * 5 + 1 : -1, n.in_prefix > 2 ? R_GX + i * 5 + 2 : -1,
+               n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
       }
-      if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
-      rc = nunet_conv3x3_fwd(&d, ls);
-      S.end();
-      if (rc) break;
       if (cv == 0) {
         if (n.in_prefix == 0) {
           // through MaxPool2d(2,2) into x_{i-1,0}
-          ls = S.begin(lane, {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0});
-          rc = nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
-                                    AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], written[i - 1][0] ? 1 : 0, ls);
-          S.end();
+          const int acc = written[i - 1][0] ? 1 : 0;
+          S.name("B%d%d.poolB", n.i, n.j);
+          S.add(lane, 0, cost_mem(5.0, 2.5 * (double)P->px[i - 1] * NBF[i - 1] * es), {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0}, [=](hipStream_t ls) {
+            return nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
+                                        AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], acc, ls);
+          });
           written[i - 1][0] = true;
         } else {
           // through the bilinear upsample into x_{i+1,up_slot}
-          ls = S.begin(lane, {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot});
-          rc = nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
-                                    AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], written[i + 1][n.up_slot] ? 1 : 0, ls);
-          S.end();
+          const int acc = written[i + 1][n.up_slot] ? 1 : 0;
+          S.name("B%d%d.upB", n.i, n.j);
+          S.add(lane, 0, cost_mem(8.0, 1.5 * (double)P->px[i] * NBF[i + 1] * es), {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot}, [=](hipStream_t ls) {
+            return nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
+                                        AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], acc, ls);
+          });
           written[i + 1][n.up_slot] = true;
         }
       }
     }
     for (int cv = 1; cv >= 0 && rc == NUNET_OK; --cv) {
       const int cidx = 2 * k + cv;
-      hipStream_t ls;
-      if (cv == 1) ls = S.begin(wlane, {rb + B_A1, wrdy[cv]}, {R_GSW + cidx});
-      else if (n.in_prefix == 0) ls = S.begin(wlane, {i == 0 ? R_IMG : rb + B_PIN, wrdy[cv]}, {R_GSW + cidx});
-      else ls = S.begin(wlane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
-                                n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, wrdy[cv]}, {R_GSW + cidx});
-      g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
-      rc = nunet_conv3x3_wgrad(&wdesc[cv], ls);
-      g_prof_alg_cin = 0;
-      S.end();
+      const nunet_wgrad_desc w = wdesc[cv];
+      const int alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
+      auto fn = [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad(&w, ls); g_prof_alg_cin = 0; return r; };
+      const float cw = cost_wg(i, (double)w.C0 + w.C1, f);
+      S.name("B%d%d.wgrad%d", n.i, n.j, cv + 1);
+      if (cv == 1) S.add(wlane, 1, cw, {rb + B_A1, wrdy[cv]}, {R_GSW + cidx}, fn);
+      else if (n.in_prefix == 0) S.add(wlane, 1, cw, {i == 0 ? R_IMG : rb + B_PIN, wrdy[cv]}, {R_GSW + cidx}, fn);
+      else S.add(wlane, 1, cw, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
+                                n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, wrdy[cv]}, {R_GSW + cidx}, fn);
     }
   }
+  if (rc == NUNET_OK) rc = S.run_ops();
   S.join();
   if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_backward: capture lane pool exhausted"); rc = NUNET_EINVAL; }
   if (rc) return rc;
@@ -882,6 +1062,27 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   ProfScope ps(PC_UNPACK, 0, (double)P->nparams * (accumulate ? 12 : 8), st);
   hipLaunchKernelGGL(unpack_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, gsr, grads, P->utab);
   return nunet_check_launch("unpack_grads");
+}
+
+extern "C" int nunet_plan_stamps_read(nunet_plan* P, int32_t pass, uint64_t* ticks, int32_t cap, int32_t* n_out, char* labels, int32_t label_bytes) {
+  NUNET_REQUIRE(P && ticks && n_out && labels && (pass == 0 || pass == 1) && label_bytes > 0, "plan_stamps_read: bad args");
+  PlanRt* rt = rt_of(P);
+  *n_out = 0; labels[0] = 0;
+  if (!rt->stamps) return NUNET_OK;                    // NUNET_STAMPS not set
+  const std::vector<std::string>& lab = rt->stamp_labels[pass];
+  int n = (int)lab.size(); if (n > cap) n = cap;
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(ticks, rt->stamps + (size_t)pass * STAMP_CAP, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+    nunet_set_error("plan_stamps_read: copy failed"); return NUNET_ELAUNCH;
+  }
+  size_t o = 0;
+  for (int k = 0; k < n; ++k) {
+    if (o + lab[k].size() + 2 > (size_t)label_bytes) break;
+    memcpy(labels + o, lab[k].c_str(), lab[k].size()); o += lab[k].size(); labels[o++] = '\n';
+  }
+  labels[o] = 0;
+  *n_out = n;
+  return NUNET_OK;
 }
 
 extern "C" int nunet_plan_set_lanes(nunet_plan* P, nunet_stream_t* lanes, int32_t n) {

@@ -59,3 +59,17 @@ extern "C" int nunet_profile_end(nunet_prof_entry* out, int32_t max_entries, int
   g_pool_used = 0;
   return NUNET_OK;
 }
+
+// Diagnostic for tools/graph_sched_probe.py: a kernel of `tag` workgroups whose first wave spins
+// for `us` microseconds of the 100 MHz wall clock (bounded: always exits). The workgroup count
+// identifies the launch in a rocprofv3 kernel trace.
+__global__ void debug_spin_kernel(int ticks) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();
+  while ((long long)(wall_clock64() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int nunet_debug_spin(int32_t us, int32_t tag, nunet_stream_t s) {
+  NUNET_REQUIRE(us >= 0 && us <= 2000 && tag >= 1 && tag <= 4096, "debug_spin: us in [0,2000], tag in [1,4096]");
+  hipLaunchKernelGGL(debug_spin_kernel, dim3(tag), dim3(64), 0, (hipStream_t)s, us * 100);
+  return nunet_check_launch("debug_spin");
+}

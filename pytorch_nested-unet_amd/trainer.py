@@ -10,6 +10,7 @@ BatchNorm statistics (plain nn.BatchNorm2d semantics, archs1.py:19,21), one
 gradient all-reduce per step over RCCL, buckets in gradient-ready order.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -138,10 +139,12 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         if self.world == 1:
-            self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb):
-                self._fwd_bwd()
-                self._opt()
+            # lane-faithful hipGraph (csrc/graph.hip): captured on a side stream, edge lists rewritten so
+            # that ROCm's node->stream assignment reproduces the plan's lanes, replayed on the caller's stream
+            self.g_fb = _NativeGraph(s, lambda: (self._fwd_bwd(), self._opt()))
+            iters = int(os.environ.get("NUNET_GRAPH_TUNE", "0"))
+            if iters > 0:
+                self.tune_result = self.g_fb.tune(iters)
         else:
             self.g_fb = torch.cuda.CUDAGraph()          # forward + loss + backward phase 1
             with torch.cuda.graph(self.g_fb):
@@ -188,6 +191,47 @@ class TrainStep:
         k = max(self.steps, 1)
         m = self.meters.tolist()
         return m[0] / k, m[1] / k
+
+
+class _NativeGraph:
+    """nunet_graph_* wrapper with the replay() surface of torch.cuda.CUDAGraph."""
+
+    def __init__(self, side_stream, body):
+        import ctypes as C
+        lib = L.lib()
+        with torch.cuda.stream(side_stream):
+            L.check(lib.nunet_graph_begin(L.stream()), "graph_begin")
+            try:
+                body()
+            finally:
+                h = C.c_void_p()
+                rc = lib.nunet_graph_end(L.stream(), C.byref(h))
+            L.check(rc, "graph_end")
+        self.handle = h
+
+    def info(self):
+        import ctypes as C
+        v = [C.c_int32() for _ in range(5)]
+        L.check(L.lib().nunet_graph_info(self.handle, *[C.byref(x) for x in v]), "graph_info")
+        return dict(zip(("nodes", "edges_captured", "edges_final", "padding", "lanes"), (x.value for x in v)))
+
+    def replay(self):
+        L.check(L.lib().nunet_graph_launch(self.handle, L.stream()), "graph_launch")
+
+    def tune(self, iters, replays=6, seed=1):
+        import ctypes as C
+        base, best = C.c_float(), C.c_float()
+        torch.cuda.synchronize()
+        L.check(L.lib().nunet_graph_tune(self.handle, iters, replays, seed, C.byref(base), C.byref(best)), "graph_tune")
+        return base.value, best.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                L.lib().nunet_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 def cosine_lr(base_lr, min_lr, epoch, t_max):

@@ -68,6 +68,9 @@ def conv_desc(dt, n, h, w, src0, c0, p0, wpack, dst0, d0, q0, src1=None, c1=0, p
     (2, 8, 40, 16, 0, 32),      # Cin = 16 (single half chunk)
     (1, 2, 2, 64, 32, 96),      # tiny spatial, Cout = 96 -> BN=32 config
     (3, 1, 1, 32, 0, 32),       # 1x1 images (level 4 of a 16x16 input)
+    (16, 12, 12, 64, 32, 64),   # 12x12 images: stacked-rows tiling (level 3 of the 96x96 workload)
+    (5, 12, 12, 32, 0, 32),     # stacked rows, BM=256 config, ragged last tile
+    (7, 3, 5, 32, 0, 64),       # stacked rows on odd tiny images
 ])
 def test_conv3x3_fwd(dt, shape):
     n, h, w, c0, c1, cout = shape
@@ -127,6 +130,8 @@ def test_conv3x3_dgrad_split_accumulate(dt):
     (5, 6, 6, 64, 32, 64, 32),      # Cin = 96: ci tile straddles the two sources
     (2, 8, 8, 32, 0, 32, 32),       # first-layer style: real Cin=3 padded to 32 handled by caller
     (3, 1, 1, 32, 0, 64, 32),
+    (16, 12, 12, 64, 32, 64, 32),   # stacked-rows tiling
+    (7, 3, 5, 32, 0, 32, 32),
 ])
 def test_conv3x3_wgrad(dt, shape):
     n, h, w, c0, c1, cout, _ = shape
