@@ -82,6 +82,8 @@ typedef struct {
 
 /* dw[tap][co][ci] += sum_p dy[p][co] * x[p+tap][ci] */
 int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s);
+/* Two independent problems (the two convolutions of one VGGBlock, archs1.py:18,20) in ONE launch. */
+int nunet_conv3x3_wgrad_pair(const nunet_wgrad_desc* a, const nunet_wgrad_desc* b, nunet_stream_t stream);
 
 /* OIHW fp32 -> packed KRSC `dtype`:
  *   wf[tap][co][ci]      (forward;  ci padded with zeros up to cin_pad)

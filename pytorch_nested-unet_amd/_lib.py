@@ -75,6 +75,7 @@ _SIG = {
     "nunet_last_error": (C.c_char_p, []),
     "nunet_conv3x3_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "nunet_conv3x3_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "nunet_conv3x3_wgrad_pair": (_i32, [C.POINTER(WgradDesc), C.POINTER(WgradDesc), _vp]),
     "nunet_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "nunet_unpack_wgrad": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "nunet_bn_relu_fwd": (_i32, [C.POINTER(BnFwdDesc), _vp]),

@@ -85,7 +85,9 @@ template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T
 
 // 16-byte vector of T with element access as float
 template <typename T> struct Vec16 {
-  u32x4 raw;
+  // zero-initialised: set() of a 16-bit element read-modify-writes its 32-bit word, and doing that on an
+  // indeterminate word is undefined (it miscompiled for fp16 on the odd elements of words 0 and 1)
+  u32x4 raw = {0u, 0u, 0u, 0u};
   __device__ __forceinline__ float get(int i) const {
     if constexpr (std::is_same<T, float>::value) {
       const uint32_t w = raw[i];  // copy first: bit_cast of a vector-element lvalue reads element 0

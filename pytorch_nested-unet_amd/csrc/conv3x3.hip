@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
       if (accum) y += o.get(e);
       v.set(e, y);
       if (p.stats) {
-        const float d = v.get(e) - b;
+        const float d = to_f32(from_f32<T>(y)) - b;   // the stored (rounded) value; not v.get(e) right after v.set(e)
         atomicAdd(&s_st[co + e], d);
         atomicAdd(&s_st[p.Cout + co + e], d * d);
       }
@@ -657,7 +657,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 // reduction, 48 accumulator registers per lane. Tiles are double-buffered in LDS; the next tile's
 // global loads are in flight (registers) while the current one multiplies.
 template <typename T>
-__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) {
+__device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
   typedef WgCfg<T> C;
   constexpr int NT = C::NT, BM = C::BM, EPV = C::EPV, SR = C::SR, UPP = C::UPP;
   __shared__ __attribute__((aligned(16))) T s_stage[2 * C::STAGE];
@@ -668,7 +668,6 @@ __global__ __launch_bounds__(192) void wgrad_kernel(WgP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
-  int bid = blockIdx.x;
   const int cit = bid % p.nCiT; bid /= p.nCiT;
   const int cot = bid % p.nCoT;
   const int split = bid / p.nCoT;
@@ -820,9 +819,20 @@ __global__ __launch_bounds__(192) void wgrad_kernel(WgP p) {
   }
 }
 
-template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStream_t st) {
+template <typename T>
+__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) { wgrad_body<T>(p, blockIdx.x); }
+
+// Two independent weight-gradient problems in ONE launch (the two convolutions of a VGGBlock finish
+// their dY at the same point of the backward pass): one kernel boundary less per block and twice
+// the workgroups to fill the chip.
+template <typename T>
+__global__ __launch_bounds__(192) void wgrad_pair_kernel(WgP pa, WgP pb, int na) {
+  if ((int)blockIdx.x < na) wgrad_body<T>(pa, blockIdx.x);
+  else wgrad_body<T>(pb, blockIdx.x - na);
+}
+
+template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p) {
   typedef WgCfg<T> C;
-  WgP p;
   p.src0 = d->src0; p.src1 = d->src1; p.C0 = d->C0; p.C1 = d->C1; p.P0 = d->P0; p.P1 = d->P1;
   p.dy = d->dy; p.Cout = d->Cout; p.PY = d->PY; p.dw = d->dw;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1;
@@ -838,16 +848,38 @@ template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStre
   if (ks > p.nMT) ks = p.nMT;
   if (ks < 1) ks = 1;
   p.ksplit = ks;
-  const long grid = (long)otiles * ks;
+  return (long)otiles * ks;
+}
+template <typename T> static void wgrad_prof(const nunet_wgrad_desc* d, const WgP& p, double& flops, double& bytes) {
   const double px = (double)d->N * d->H * d->W;
   const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
-  ProfScope ps(p.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, 2.0 * 9 * acin * p.Cout * px,
-               px * (acin + p.Cout) * sizeof(T) + 9.0 * acin * p.Cout * 4, st);
+  flops = 2.0 * 9 * acin * p.Cout * px;
+  bytes = px * (acin + p.Cout) * sizeof(T) + 9.0 * acin * p.Cout * 4;
+}
+
+template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStream_t st) {
+  typedef WgCfg<T> C;
+  WgP p;
+  const long grid = wgrad_setup<T>(d, p);
+  double fl, by; wgrad_prof<T>(d, p, fl, by);
+  ProfScope ps(p.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fl, by, st);
   hipLaunchKernelGGL((wgrad_kernel<T>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   return nunet_check_launch("wgrad3x3");
 }
 
-extern "C" int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s) {
+struct WgPairArgs { const nunet_wgrad_desc* a; const nunet_wgrad_desc* b; };
+template <typename T> static int launch_wgrad_pair(const WgPairArgs* w, hipStream_t st) {
+  typedef WgCfg<T> C;
+  WgP pa, pb;
+  const long ga = wgrad_setup<T>(w->a, pa), gb = wgrad_setup<T>(w->b, pb);
+  double fa, ba, fb, bb; wgrad_prof<T>(w->a, pa, fa, ba);
+  { const int keep = g_prof_alg_cin; g_prof_alg_cin = 0; wgrad_prof<T>(w->b, pb, fb, bb); g_prof_alg_cin = keep; }
+  ProfScope ps(pa.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fa + fb, ba + bb, st);
+  hipLaunchKernelGGL((wgrad_pair_kernel<T>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
+  return nunet_check_launch("wgrad3x3 (pair)");
+}
+
+static int wgrad_check(const nunet_wgrad_desc* d) {
   NUNET_REQUIRE(d && d->src0 && d->dy && d->dw, "wgrad: null pointer");
   NUNET_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "wgrad: bad extent");
   NUNET_REQUIRE(d->C0 > 0 && d->C0 % 16 == 0 && d->C1 % 16 == 0, "wgrad: C0=%d C1=%d must be multiples of 16", d->C0, d->C1);
@@ -856,5 +888,19 @@ extern "C" int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s) 
   const int epv = 16 / dtype_size(d->dtype);
   NUNET_REQUIRE(d->P0 % epv == 0 && (d->C1 == 0 || d->P1 % epv == 0) && d->PY % epv == 0, "wgrad: pitch alignment");
   NUNET_REQUIRE((long)d->N * d->H * d->W < (1L << 30), "wgrad: too many pixels");
+  return NUNET_OK;
+}
+extern "C" int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s) {
+  int rc = wgrad_check(d);
+  if (rc) return rc;
   return NUNET_DISPATCH(d->dtype, launch_wgrad, d, (hipStream_t)s);
+}
+extern "C" int nunet_conv3x3_wgrad_pair(const nunet_wgrad_desc* a, const nunet_wgrad_desc* b, nunet_stream_t s) {
+  int rc = wgrad_check(a);
+  if (rc) return rc;
+  rc = wgrad_check(b);
+  if (rc) return rc;
+  NUNET_REQUIRE(a->dtype == b->dtype, "wgrad_pair: the two problems must share the dtype");
+  WgPairArgs w{a, b};
+  return NUNET_DISPATCH(a->dtype, launch_wgrad_pair, &w, (hipStream_t)s);
 }

@@ -154,6 +154,38 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   const int G = p.C / EPV;  // channel groups; 256 % G == 0
   const int cg = threadIdx.x % G;
   const float M = (float)p.N * p.H * p.W;
+  // first batch of loads ahead of the coefficient prologue (latencies overlap)
+  constexpr int U = 4;   // 16-byte loads kept in flight per thread
+  const int ppb0 = blockDim.x / G, pl0 = threadIdx.x / G;
+  const int64_t npix0 = (int64_t)p.N * p.H * p.W;
+  const int64_t stride0 = (int64_t)gridDim.x * ppb0;
+  Vec16<T> v[U];
+  auto load_batch = [&](int64_t p0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pix = p0 + u * stride0;
+      if (pix < npix0) v[u] = ld16((const T*)p.y + pix * p.PY + cg * EPV);
+    }
+  };
+  int64_t pix0 = (int64_t)blockIdx.x * ppb0 + pl0;
+  if constexpr (!POOL) { if (pix0 < npix0) load_batch(pix0); }
+  const int H2 = p.H / 2, W2 = p.W / 2;
+  const int64_t nq = (int64_t)p.N * H2 * W2;
+  Vec16<T> vq[4];
+  auto quad_base = [&](int64_t q) {
+    const int qx = (int)(q % W2);
+    const int64_t t = q / W2;
+    const int qy = (int)(t % H2);
+    const int n = (int)(t / H2);
+    return ((int64_t)n * p.H + 2 * qy) * p.W + 2 * qx;
+  };
+  auto qload = [&](int64_t q) {
+    const int64_t p00 = quad_base(q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vq[k] = ld16((const T*)p.y + (p00 + (k >> 1) * p.W + (k & 1)) * p.PY + cg * EPV);
+  };
+  const int64_t q0 = (int64_t)blockIdx.x * ppb0 + pl0;
+  if constexpr (POOL) { if (q0 < nq) qload(q0); }
   // per-channel coefficients once per block (not per thread), block 0 also owns the
   // running-stat update and the saved mean/invstd for backward
   for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
@@ -180,16 +212,8 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   const int ppb = blockDim.x / G;  // pixels (or quads) per block iteration
   const int pl = threadIdx.x / G;
   if constexpr (!POOL) {
-    const int64_t npix = (int64_t)p.N * p.H * p.W;
-    const int64_t stride = (int64_t)gridDim.x * ppb;
-    constexpr int U = 4;   // 16-byte loads kept in flight per thread
-    for (int64_t pix0 = (int64_t)blockIdx.x * ppb + pl; pix0 < npix; pix0 += U * stride) {
-      Vec16<T> v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t pix = pix0 + u * stride;
-        if (pix < npix) v[u] = ld16((const T*)p.y + pix * p.PY + cg * EPV);
-      }
+    const int64_t npix = npix0, stride = stride0;
+    while (pix0 < npix) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t pix = pix0 + u * stride;
@@ -200,27 +224,28 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
           st16((T*)p.a + pix * p.PA + cg * EPV, o);
         }
       }
+      pix0 += U * stride;
+      if (pix0 < npix) load_batch(pix0);
     }
   } else {
-    const int H2 = p.H / 2, W2 = p.W / 2;
-    const int64_t nq = (int64_t)p.N * H2 * W2;
-    for (int64_t q = (int64_t)blockIdx.x * ppb + pl; q < nq; q += (int64_t)gridDim.x * ppb) {
-      const int qx = (int)(q % W2);
-      const int64_t t = q / W2;
-      const int qy = (int)(t % H2);
-      const int n = (int)(t / H2);
-      const int64_t p00 = ((int64_t)n * p.H + 2 * qy) * p.W + 2 * qx;
+    // (the quad loads of the first iteration were issued ahead of the prologue, see qload)
+    int64_t q = q0;
+    while (q < nq) {
+      const int64_t p00 = quad_base(q);
       float mx[EPV];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int64_t pix = p00 + (k >> 1) * p.W + (k & 1);
-        Vec16<T> v = ld16((const T*)p.y + pix * p.PY + cg * EPV);
+        const Vec16<T> v = vq[k];
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
           const float a = fmaxf(v.get(e) * sc[e] + sh[e], 0.f);
           o.set(e, a);
-          const float ar = o.get(e);  // rounded value, as a later pool would see it
+          // rounded value, as a later pool would see it (rounded explicitly: reading it back with o.get(e)
+          // right after o.set(e) miscompiled for fp16 on the odd lanes of the packed words)
+          float ar = to_f32(from_f32<T>(a));
+          asm volatile("" : "+v"(ar));   // keep the running maximum in fp32 registers (see above)
           mx[e] = (k == 0) ? ar : fmaxf(mx[e], ar);
         }
         st16((T*)p.a + pix * p.PA + cg * EPV, o);
@@ -229,6 +254,8 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
 #pragma unroll
       for (int e = 0; e < EPV; ++e) po.set(e, mx[e]);
       st16((T*)p.pooled + q * p.PP + cg * EPV, po);
+      q += (int64_t)gridDim.x * ppb;
+      if (q < nq) qload(q);
     }
   }
 }
@@ -286,6 +313,24 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
   const int ppb = blockDim.x / G, pl = threadIdx.x / G;
   const float M = (float)p.N * p.H * p.W;
   const int C = p.C;
+  // the first batch of activation loads is issued BEFORE the per-channel coefficient prologue, so the two
+  // global-memory latencies overlap (the small pyramid levels run exactly one iteration per thread)
+  const int64_t npix = (int64_t)p.N * p.H * p.W;
+  const int64_t stride = (int64_t)gridDim.x * ppb;
+  constexpr int U = 4;   // pixels per thread per iteration: 8 sixteen-byte loads in flight
+  Vec16<T> vy[U], vd[U];
+  auto load_batch = [&](int64_t p0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pix = p0 + u * stride;
+      if (pix < npix) {
+        vy[u] = ld16((const T*)p.y + pix * p.PY + cg * EPV);
+        vd[u] = ld16((const T*)p.da + pix * p.PDA + cg * EPV);
+      }
+    }
+  };
+  int64_t pix0 = (int64_t)blockIdx.x * ppb + pl;
+  if (pix0 < npix) load_batch(pix0);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float mean = p.mi[c], istd = p.mi[C + c];
     const float sc = p.gamma[c] * istd;
@@ -303,19 +348,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
   float a1[EPV], a2[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
-  const int64_t npix = (int64_t)p.N * p.H * p.W;
-  const int64_t stride = (int64_t)gridDim.x * ppb;
-  constexpr int U = 4;   // pixels per thread per iteration: 8 sixteen-byte loads in flight
-  for (int64_t pix0 = (int64_t)blockIdx.x * ppb + pl; pix0 < npix; pix0 += U * stride) {
-    Vec16<T> vy[U], vd[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t pix = pix0 + u * stride;
-      if (pix < npix) {
-        vy[u] = ld16((const T*)p.y + pix * p.PY + cg * EPV);
-        vd[u] = ld16((const T*)p.da + pix * p.PDA + cg * EPV);
-      }
-    }
+  while (pix0 < npix) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t pix = pix0 + u * stride;
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
           if constexpr (APPLY) {
             const float dyv = sc[e] * (dz - k1[e] - xh * k2[e]);
             o.set(e, dyv);
-            a1[e] += o.get(e);
+            a1[e] += to_f32(from_f32<T>(dyv));   // the stored (rounded) value; not o.get(e): see bn_relu_fwd_kernel
           } else {
             a1[e] += dz;
             a2[e] += dz * xh;
@@ -339,6 +372,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
         if constexpr (APPLY) st16((T*)p.dy + pix * p.PDY + cg * EPV, o);
       }
     }
+    pix0 += U * stride;
+    if (pix0 < npix) load_batch(pix0);
   }
   // block reduction over the ppb threads that share a channel group, then one atomic per channel
 #pragma unroll

@@ -561,11 +561,11 @@ struct Sched {
   // ops (weight gradients: nothing but the final unpack consumes them) float to whichever lane is
   // idle. Conflicting ops (RAW/WAW/WAR on a resource) keep their program order, so the events
   // derived at issue time are the ones program order would give.
-  struct Op { int lane, leaf; float cost; int nrd, nwr; int rd[8], wr[8]; char name[32]; std::function<int(hipStream_t)> fn; };
+  struct Op { int lane, leaf; float cost; int nrd, nwr; int rd[12], wr[8]; char name[32]; std::function<int(hipStream_t)> fn; };
   std::vector<Op> ops;
   void add(int lane, int leaf, float cost, std::initializer_list<int> rd, std::initializer_list<int> wr, std::function<int(hipStream_t)> fn) {
     Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0;
-    for (int x : rd) if (x >= 0 && o.nrd < 8) o.rd[o.nrd++] = x;
+    for (int x : rd) if (x >= 0 && o.nrd < 12) o.rd[o.nrd++] = x;
     for (int x : wr) if (x >= 0 && o.nwr < 8) o.wr[o.nwr++] = x;
     memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
     o.fn = std::move(fn);
@@ -1038,7 +1038,22 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
         }
       }
     }
-    for (int cv = 1; cv >= 0 && rc == NUNET_OK; --cv) {
+    static int wg_pair = -1;
+    if (wg_pair < 0) { const char* e = getenv("NUNET_WGRAD_PAIR"); wg_pair = e ? atoi(e) : 1; }
+    if (wg_pair && rc == NUNET_OK) {
+      // both weight gradients of the block in one launch (conv1's problem first: it may carry the
+      // first layer's algorithmic Cin for the profiler)
+      const nunet_wgrad_desc w0 = wdesc[0], w1 = wdesc[1];
+      const int alg_cin = (i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
+      const float cw = cost_wg(i, (double)w0.C0 + w0.C1, f) + cost_wg(i, (double)w1.C0 + w1.C1, f) - 8.f;
+      S.name("B%d%d.wgrad", n.i, n.j);
+      int rx[4] = {-1, -1, -1, -1}, r_in = -1, r_up = -1;
+      if (n.in_prefix == 0) r_in = (i == 0 ? R_IMG : rb + B_PIN);
+      else { for (int q = 0; q < n.in_prefix && q < 4; ++q) rx[q] = R_X + i * 5 + q; r_up = rb + B_UP; }
+      S.add(wlane, 1, cw, {rb + B_A1, wrdy[1], wrdy[0], r_in, rx[0], rx[1], rx[2], rx[3], r_up}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
+            [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w0, &w1, ls); g_prof_alg_cin = 0; return r; });
+    }
+    for (int cv = 1; cv >= 0 && rc == NUNET_OK && !wg_pair; --cv) {
       const int cidx = 2 * k + cv;
       const nunet_wgrad_desc w = wdesc[cv];
       const int alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;

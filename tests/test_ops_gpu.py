@@ -153,6 +153,36 @@ def test_conv3x3_wgrad(dt, shape):
     assert rel_err(got, wt.grad) < (5e-5 if dt == L.F32 else 1e-3), (DT[dt], shape)   # inputs are exact in T; only fp32 accumulation differs
 
 
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+def test_conv3x3_wgrad_pair(dt):
+    """Two independent weight-gradient problems in one launch equal two single launches
+    (the two convolutions of a VGGBlock, reference archs1.py:18,20)."""
+    n, h, w = 3, 12, 12
+    g = torch.Generator().manual_seed(5)
+    probs = [(64, 32, 64), (64, 0, 64)]        # (C0, C1, Cout): conv1 with a concat input, conv2 mid -> out
+    descs, keep, refs, dws = [], [], [], []
+    for c0, c1, cout in probs:
+        cin = c0 + c1
+        x = torch.randn(n, cin, h, w, generator=g)
+        dy = torch.randn(n, cout, h, w, generator=g)
+        s0 = nhwc(x[:, :c0], dt, pitch=c0 + 32)
+        s1 = nhwc(x[:, c0:], dt) if c1 else None
+        dyb = nhwc(dy, dt)
+        dw = torch.zeros(9 * cout * cin, dtype=torch.float32, device=DEV)
+        keep += [s0, s1, dyb]
+        dws.append(dw)
+        descs.append(L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, c0 + 32, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(dw)))
+        ref = torch.zeros_like(dw)
+        d1 = L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, c0 + 32, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(ref))
+        L.check(L.lib().nunet_conv3x3_wgrad(C.byref(d1), L.stream()), "wgrad")
+        refs.append(ref)
+    L.check(L.lib().nunet_conv3x3_wgrad_pair(C.byref(descs[0]), C.byref(descs[1]), L.stream()), "wgrad_pair")
+    torch.cuda.synchronize()
+    for dw, ref in zip(dws, refs):
+        assert float(ref.abs().max()) > 0
+        assert rel_err(dw.cpu(), ref.cpu()) < 1e-5      # same arithmetic, only the atomic order differs
+
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 def test_pack_unpack_roundtrip(dt):
     g = torch.Generator().manual_seed(5)
@@ -173,7 +203,7 @@ def test_pack_unpack_roundtrip(dt):
     np.testing.assert_allclose(gg.view(64, 3, 3, 3).cpu().numpy(), exp.numpy(), rtol=1e-6)
 
 
-@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_relu_fwd(dt, pool, training):
@@ -219,7 +249,7 @@ def test_bn_relu_fwd(dt, pool, training):
         assert torch.equal(rmg.cpu(), rm) and int(nbt.item()) == 4
 
 
-@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
 def test_bn_relu_bwd(dt):
     n, h, w, c = 3, 8, 12, 64
     g = torch.Generator().manual_seed(4)
