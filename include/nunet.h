@@ -47,6 +47,12 @@ const char* nunet_last_error(void);
 /* 3x3 convolution, pad 1, stride 1 (nn.Conv2d(ci,co,3,padding=1),           */
 /* reference finished/archs1.py:18,20) and its two gradients.                */
 /* ------------------------------------------------------------------------ */
+/* Per-channel reduction buffers that thousands of workgroups add to (BatchNorm backward sums) are
+ * replicated: a workgroup adds to replica (its index mod r), r = clamp(256 / C, 1, NUNET_BN_SUM_REPLICAS),
+ * the consumer sums those r replicas (replica stride 2*C floats). Same-address global atomics serialise at ~12 ns each on MI355X; 576 workgroups on one
+ * address cost 7 us at the end of a 14 us kernel. */
+#define NUNET_BN_SUM_REPLICAS 8
+
 typedef struct {
   int32_t dtype;
   int32_t N, H, W;
@@ -65,6 +71,14 @@ typedef struct {
   float* stats;                     /* [2][Cout] fp32: += sum(y-b), sum((y-b)^2) or NULL */
   float* splitk_ws;                 /* optional fp32 scratch: lets grid-starved layers split the contraction */
   int64_t splitk_ws_floats;         /* over workgroups (S slabs of N*H*W*Cout floats). NULL: never split */
+  /* Optional fused BatchNorm+ReLU backward REDUCE (used for the dgrad of a block's second conv, whose
+   * output is the gradient entering the first conv's BN, archs1.py:18-19): with z = relu(bn(bn_y)),
+   * dz = (z > 0) ? dst0 : 0, bn_sums[c] += sum dz, bn_sums[Cout + c] += sum dz * xhat. Needs D1 == 0,
+   * Q0 == D0, no accumulation. NULL bn_y: off (nunet_bn_relu_bwd_reduce does the same as its own pass). */
+  const void* bn_y; int32_t bn_py;  /* raw output of the BN's conv, [N*H*W][bn_py] */
+  const float* bn_mean_invstd;      /* [2][Cout] saved by nunet_bn_relu_fwd */
+  const float* bn_gamma; const float* bn_beta;
+  float* bn_sums;                   /* [NUNET_BN_SUM_REPLICAS][2][Cout], pre-zeroed (same buffer nunet_bn_relu_bwd_apply reads) */
 } nunet_conv_desc;
 
 /* y = conv(cat(src0,src1)) + bias. Also used as dgrad with the flipped,
@@ -120,7 +134,7 @@ typedef struct {
   const void* y;  int32_t PY;
   const float* mean_invstd;         /* [2][C] */
   const float* gamma; const float* beta;
-  float* sums;                      /* [2][C] scratch, zeroed by caller: sum dz, sum dz*xhat */
+  float* sums;                      /* [NUNET_BN_SUM_REPLICAS][2][C] scratch, zeroed by caller: sum dz, sum dz*xhat */
   float* dgamma; float* dbeta;      /* [C] += */
   float* dbias;                     /* [C] += sum dy (conv bias grad) */
   void* dy; int32_t PDY;            /* grad wrt raw conv output */

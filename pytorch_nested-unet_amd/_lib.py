@@ -19,6 +19,7 @@ DTYPES = {"fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 _vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+BN_SUM_REPLICAS = 8        # NUNET_BN_SUM_REPLICAS in include/nunet.h
 
 
 class ConvDesc(C.Structure):
@@ -29,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("dst0", _vp), ("D0", _i32), ("Q0", _i32),
                 ("dst1", _vp), ("D1", _i32), ("Q1", _i32),
                 ("acc_slot_w", _i32), ("acc0_mask", _u32), ("acc1", _i32),
-                ("stats", _vp), ("splitk_ws", _vp), ("splitk_ws_floats", _i64)]
+                ("stats", _vp), ("splitk_ws", _vp), ("splitk_ws_floats", _i64),
+                ("bn_y", _vp), ("bn_py", _i32), ("bn_mean_invstd", _vp), ("bn_gamma", _vp), ("bn_beta", _vp), ("bn_sums", _vp)]
 
 
 class WgradDesc(C.Structure):

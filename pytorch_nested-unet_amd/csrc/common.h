@@ -84,6 +84,14 @@ template <typename T> __device__ __forceinline__ float to_f32(T v) { return (flo
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
 // 16-byte vector of T with element access as float
+// Replicas of a per-channel sum buffer actually used for C channels (include/nunet.h, NUNET_BN_SUM_REPLICAS):
+// contention is a matter of the shallow, wide levels (many workgroups, few channels); deep levels have
+// few workgroups and reading 8 x 2 x C values per consumer block would cost more than it saves.
+__host__ __device__ __forceinline__ int bn_sum_replicas(int C) {
+  const int r = 256 / C;
+  return r < 1 ? 1 : (r > NUNET_BN_SUM_REPLICAS ? NUNET_BN_SUM_REPLICAS : r);
+}
+
 template <typename T> struct Vec16 {
   // zero-initialised: set() of a 16-bit element read-modify-writes its 32-bit word, and doing that on an
   // indeterminate word is undefined (it miscompiled for fp16 on the odd elements of words 0 and 1)

@@ -88,6 +88,11 @@ struct ConvP {
   int S, nch0, nch;      // K-split: slices, channel chunks of source 0 / total (SK kernels only)
   float* slabs;          // [S][pixels][Cout] fp32 partial sums
   long long slab_stride; // pixels * Cout
+  // BNR kernels (dgrad of a block's second conv): the BatchNorm+ReLU backward REDUCE pass of the first
+  // conv's BN is taken in the epilogue, on the values just stored (dst0 must be dense and assign-only)
+  const void* bn_y; int bn_py;            // raw output of the first conv (what that BN normalised)
+  const float* bn_mi; const float* bn_gamma; const float* bn_beta;   // saved mean | invstd, affine
+  float* bn_sums;                         // [2][Cout]: sum dz, sum dz * xhat (atomically accumulated)
 };
 
 template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
@@ -113,7 +118,7 @@ template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
 // The global loads of the NEXT (item, channel chunk) are issued into registers before the
 // current chunk's MFMA sweep, so HBM latency hides under compute and under the previous
 // tile's epilogue, and co-resident workgroups de-synchronise their load/compute/store phases.
-template <typename T, int WM, int WN, int SM, int SN, bool SK>
+template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
   typedef Mma<T> M;
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   __shared__ int s_hxy[C::HPMAX];    // tile-invariant: packed (ni, hy, hx) of halo pixel, -1 unused
   __shared__ int s_gpix[BM];         // per item: global pixel of row m, -1 masked
   __shared__ float s_red[2 * WM * BN];
+  __shared__ float s_bnc[BNR ? 4 * 512 : 1];   // BNR: [mean | invstd | scale | shift][Cout <= 512], loaded once
   T* const s_halo = s_buf;
   T* const s_w = s_buf + C::HALO_ELEMS;
 
@@ -153,6 +159,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       code = (ni << 20) | (hy << 10) | hx;
     }
     s_hxy[hp] = code;
+  }
+  if constexpr (BNR) {
+    for (int c = tid; c < p.Cout; c += NT) {
+      const float mean = p.bn_mi[c], istd = p.bn_mi[p.Cout + c];
+      const float sc = p.bn_gamma[c] * istd;
+      s_bnc[c] = mean; s_bnc[512 + c] = istd; s_bnc[1024 + c] = sc; s_bnc[1536 + c] = p.bn_beta[c] - mean * sc;
+    }
   }
   __syncthreads();
 
@@ -347,6 +360,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       cur = nxt; item = nitem; first_chunk = true;
     } else if (last_chunk) {
       // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
+      // BNR: the y1 vectors of this thread's store units are requested NOW, so their latency hides under
+      // the accumulator -> LDS transposition below instead of being exposed once per unit in the store loop
+      Vec16<T> byv[BNR ? C::UO : 1];
+      if constexpr (BNR) {
+        constexpr int SEGS0 = BN / EPV;
+#pragma unroll
+        for (int k = 0; k < C::UO; ++k) {
+          const int u = tid + k * NT;
+          const int m = u / SEGS0, seg = u - m * SEGS0;
+          const int gp = m < BM ? s_gpix[m] : -1;
+#if defined(NUNET_ABL) && (NUNET_ABL & 16)
+          if (gp >= 0 && p.N < 0) byv[k] = ld16((const T*)p.bn_y + (size_t)gp * p.bn_py + cur.co0 + seg * EPV);
+#else
+          if (gp >= 0) byv[k] = ld16((const T*)p.bn_y + (size_t)gp * p.bn_py + cur.co0 + seg * EPV);
+#endif
+        }
+      }
       __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
       T* const s_out = s_buf;
 #pragma unroll
@@ -376,6 +406,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       }
       __syncthreads();
       constexpr int SEGS = BN / EPV;
+      // BNR: every unit of a thread has the same channel segment (NT % SEGS == 0), so the BN-backward
+      // partial sums of its 8 channels live in registers across the store loop
+      float bmean[BNR ? EPV : 1], bistd[BNR ? EPV : 1], bsc[BNR ? EPV : 1], bsh[BNR ? EPV : 1], r1[BNR ? EPV : 1], r2[BNR ? EPV : 1];
+      if constexpr (BNR) {
+        const int c0 = cur.co0 + (tid % SEGS) * EPV;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          bmean[e] = s_bnc[c0 + e]; bistd[e] = s_bnc[512 + c0 + e]; bsc[e] = s_bnc[1024 + c0 + e]; bsh[e] = s_bnc[1536 + c0 + e];
+          r1[e] = 0.f; r2[e] = 0.f;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < C::UO; ++k) {
         const int u = tid + k * NT;
@@ -403,7 +444,52 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
               for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + o.get(e));
             }
             st16(q, v);
+#if defined(NUNET_ABL) && (NUNET_ABL & 32)
+            if constexpr (BNR) if (p.N < 0) {
+#else
+            if constexpr (BNR) {
+#endif
+              const Vec16<T> yv = byv[k];
+#pragma unroll
+              for (int e = 0; e < EPV; ++e) {
+                const float yy = yv.get(e);
+                const float dz = (yy * bsc[e] + bsh[e]) > 0.f ? v.get(e) : 0.f;   // the stored (rounded) gradient
+                r1[e] += dz;
+                r2[e] += dz * ((yy - bmean[e]) * bistd[e]);
+              }
+            }
           }
+        }
+      }
+      if constexpr (BNR) {
+        // lanes that share a channel segment (lane % SEGS) are summed with xor-shuffles, the four waves
+        // through a small LDS table, then one atomic per channel and sum
+#if !(defined(NUNET_ABL) && (NUNET_ABL & 64))
+#pragma unroll
+        for (int off = SEGS; off < 64; off <<= 1) {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) { r1[e] += __shfl_xor(r1[e], off); r2[e] += __shfl_xor(r2[e], off); }
+        }
+#endif
+        __syncthreads();                                   // s_out reads of the store loop are done
+        float* s_bn = reinterpret_cast<float*>(s_buf);     // [waves][2][BN]
+        if (lane < SEGS) {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) {
+            s_bn[(wave * 2 + 0) * BN + lane * EPV + e] = r1[e];
+            s_bn[(wave * 2 + 1) * BN + lane * EPV + e] = r2[e];
+          }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += NT) {
+          const int vsel = t / BN, c = t - vsel * BN;
+          float sum = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < WM * WN; ++wv) sum += s_bn[(wv * 2 + vsel) * BN + c];
+#if defined(NUNET_ABL) && (NUNET_ABL & 128)
+          if (p.N < 0)
+#endif
+          atomicAdd(&p.bn_sums[((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c], sum);
         }
       }
       if (p.stats) {
@@ -428,13 +514,23 @@ struct SplitFinP {
   const float* slabs; long long slab_stride; int S; const float* bias;
   void* dst0; void* dst1; int D0, D1, Q0, Q1; int slot_w; unsigned acc0_mask; int acc1;
   float* stats; long long npix; int Cout;
+  const void* bn_y; int bn_py; const float* bn_mi; const float* bn_gamma; const float* bn_beta; float* bn_sums;   // see ConvP
 };
-template <typename T>
+template <typename T, bool BNR = false>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
   constexpr int EPV = Tr<T>::EPV;
   __shared__ float s_st[2 * 1024];
+  __shared__ float s_bn[BNR ? 6 * 1024 : 1];   // [mean | invstd | scale | shift | sum dz | sum dz*xhat][Cout]
   const int G = p.Cout / EPV;
   if (p.stats) for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x) s_st[c] = 0.f;
+  if constexpr (BNR) {
+    for (int c = threadIdx.x; c < p.Cout; c += blockDim.x) {
+      const float mean = p.bn_mi[c], istd = p.bn_mi[p.Cout + c];
+      const float sc = p.bn_gamma[c] * istd;
+      s_bn[c] = mean; s_bn[p.Cout + c] = istd; s_bn[2 * p.Cout + c] = sc; s_bn[3 * p.Cout + c] = p.bn_beta[c] - mean * sc;
+      s_bn[4 * p.Cout + c] = 0.f; s_bn[5 * p.Cout + c] = 0.f;
+    }
+  }
   __syncthreads();
   const long long total = p.npix * G;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -471,6 +567,22 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
       }
     }
     st16(q, v);
+    if constexpr (BNR) {
+      const Vec16<T> yv = ld16((const T*)p.bn_y + pix * p.bn_py + co);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const int c = co + e;
+        const float yy = yv.get(e);
+        const float dz = (yy * s_bn[2 * p.Cout + c] + s_bn[3 * p.Cout + c]) > 0.f ? v.get(e) : 0.f;
+        atomicAdd(&s_bn[4 * p.Cout + c], dz);
+        atomicAdd(&s_bn[5 * p.Cout + c], dz * ((yy - s_bn[c]) * s_bn[p.Cout + c]));
+      }
+    }
+  }
+  if constexpr (BNR) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x)
+      atomicAdd(&p.bn_sums[(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout + c], s_bn[4 * p.Cout + c]);
   }
   if (p.stats) {
     __syncthreads();
@@ -529,6 +641,8 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.slot_w = d->acc_slot_w; p.acc0_mask = d->acc0_mask; p.acc1 = d->acc1;
   p.stats = d->stats;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1; p.Cout = d->D0 + d->D1;
+  const bool bnr = d->bn_y != nullptr;
+  p.bn_y = d->bn_y; p.bn_py = d->bn_py; p.bn_mi = d->bn_mean_invstd; p.bn_gamma = d->bn_gamma; p.bn_beta = d->bn_beta; p.bn_sums = d->bn_sums;
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
   p.nCoT = p.Cout / C::BN;
@@ -550,7 +664,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   }
   p.nItems = (int)items;
   // persistent grid: resident workgroups only, item counts balanced across them
-  const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN;
+  const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN + (d->bn_y ? 8192 : 0);
   long per_cu = (long)(160 * 1024 / lds_bytes);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2048 / C::NT) per_cu = 2048 / C::NT;
@@ -568,12 +682,15 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
     f.dst0 = p.dst0; f.dst1 = p.dst1; f.D0 = p.D0; f.D1 = p.D1; f.Q0 = p.Q0; f.Q1 = p.Q1;
     f.slot_w = p.slot_w; f.acc0_mask = p.acc0_mask; f.acc1 = p.acc1; f.stats = p.stats;
     f.npix = (long long)d->N * d->H * d->W; f.Cout = p.Cout;
+    f.bn_y = p.bn_y; f.bn_py = p.bn_py; f.bn_mi = p.bn_mi; f.bn_gamma = p.bn_gamma; f.bn_beta = p.bn_beta; f.bn_sums = p.bn_sums;
     long long fg = (f.npix * (p.Cout / C::EPV) + 255) / 256;
     if (fg > 1024) fg = 1024;
-    hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3((unsigned)fg), dim3(256), 0, st, f);
+    if (bnr) hipLaunchKernelGGL((splitk_finalize_kernel<T, true>), dim3((unsigned)fg), dim3(256), 0, st, f);
+    else hipLaunchKernelGGL((splitk_finalize_kernel<T, false>), dim3((unsigned)fg), dim3(256), 0, st, f);
     return nunet_check_launch("conv3x3 (K-split)");
   }
-  hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  if (bnr) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  else hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   return nunet_check_launch("conv3x3");
 }
 
@@ -605,6 +722,11 @@ extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {
   NUNET_REQUIRE(d->P0 % epv == 0 && (d->C1 == 0 || d->P1 % epv == 0), "conv3x3: source pitch must keep 16-byte alignment");
   NUNET_REQUIRE(d->acc_slot_w == 0 || d->acc_slot_w % 32 == 0, "conv3x3: acc_slot_w %d", d->acc_slot_w);
   NUNET_REQUIRE((long)d->N * d->H * d->W < (1L << 30) && cin <= 4096, "conv3x3: problem too large for 32-bit pixel indices");
+  if (d->bn_y) {
+    NUNET_REQUIRE(d->bn_mean_invstd && d->bn_gamma && d->bn_beta && d->bn_sums, "conv3x3: fused BN-backward reduce needs mean/invstd, gamma, beta and sums");
+    NUNET_REQUIRE(d->D1 == 0 && d->Q0 == d->D0 && d->acc0_mask == 0 && d->bn_py % (16 / dtype_size(d->dtype)) == 0 && cout <= 512,
+                  "conv3x3: fused BN-backward reduce needs one dense, assign-only destination");
+  }
   return NUNET_DISPATCH(d->dtype, launch_conv, d, (hipStream_t)s);
 }
 

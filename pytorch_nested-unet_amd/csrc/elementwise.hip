@@ -335,7 +335,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
     const float mean = p.mi[c], istd = p.mi[C + c];
     const float sc = p.gamma[c] * istd;
     s_co[c] = mean; s_co[C + c] = istd; s_co[2 * C + c] = sc; s_co[3 * C + c] = p.beta[c] - mean * sc;
-    if constexpr (APPLY) { s_co[4 * C + c] = p.sums[c] / M; s_co[5 * C + c] = p.sums[C + c] / M; }
+    if constexpr (APPLY) {
+      float t1 = 0.f, t2 = 0.f;
+      const int nrep = bn_sum_replicas(C);
+      for (int r = 0; r < nrep; ++r) { t1 += p.sums[(r * 2 + 0) * C + c]; t2 += p.sums[(r * 2 + 1) * C + c]; }
+      s_co[4 * C + c] = t1 / M; s_co[5 * C + c] = t2 / M;
+    }
   }
   __syncthreads();
   float sc[EPV], sh[EPV], mean[EPV], istd[EPV], k1[EPV], k2[EPV];
@@ -388,13 +393,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
     float sum = 0.f;
     for (int q = 0; q < ppb; ++q) sum += s_part[((q * G + g) * NV + v) * EPV + e];
     if constexpr (APPLY) { if (p.dbias) atomicAdd(&p.dbias[c], sum); }
-    else atomicAdd(&p.sums[v * C + c], sum);
+    else atomicAdd(&p.sums[((blockIdx.x & (bn_sum_replicas(C) - 1)) * 2 + v) * C + c], sum);
   }
   if constexpr (APPLY) {
     if (blockIdx.x == 0) {
       for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        if (p.dbeta) p.dbeta[c] += p.sums[c];
-        if (p.dgamma) p.dgamma[c] += p.sums[C + c];
+        if (p.dbeta) p.dbeta[c] += s_co[4 * C + c] * M;
+        if (p.dgamma) p.dgamma[c] += s_co[5 * C + c] * M;
       }
     }
   }

@@ -326,7 +326,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   size_t cur = 0;
   P->stats_floats = (size_t)sv;
   P->off_stats = bump(cur, P->stats_floats * 4);
-  P->gs_floats = (size_t)gs + (size_t)sv;  // grad scratch followed by bn-bwd sums
+  P->gs_floats = (size_t)gs + (size_t)sv * NUNET_BN_SUM_REPLICAS;  // grad scratch followed by the (replicated) bn-bwd sums
   P->off_gs = bump(cur, P->gs_floats * 4);
   P->off_save = bump(cur, (size_t)sv * 4);
   P->off_wpack = bump(cur, (size_t)wp * P->es);
@@ -847,7 +847,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       d.wpack = wpack + (size_t)L.wf * es;
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
       d.dst0 = AB(arena, cv == 0 ? n.y1 : n.y2); d.D0 = f; d.Q0 = f;
-      d.stats = training ? stats + L.stats : nullptr;
+      d.stats = (training && !getenv("NUNET_DBG_NOSTATS")) ? stats + L.stats : nullptr;   // NUNET_DBG_NOSTATS: timing experiment only (wrong results)
       if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
       g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
       rc = nunet_conv3x3_fwd(&d, ls);
@@ -903,7 +903,7 @@ extern "C" int nunet_plan_grad_scratch(const nunet_plan* P, int64_t* byte_offset
   NUNET_REQUIRE(P && byte_offset && bucket0_floats && total_floats, "plan_grad_scratch: null pointer");
   *byte_offset = (int64_t)P->off_gs;
   *bucket0_floats = P->gs_bucket0;
-  *total_floats = (int64_t)(P->gs_floats - P->stats_floats);
+  *total_floats = (int64_t)(P->gs_floats - P->stats_floats * NUNET_BN_SUM_REPLICAS);
   return NUNET_OK;
 }
 
@@ -915,7 +915,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   const nunet_plan_cfg& c = P->cfg;
   const int dt = c.dtype, es = P->es;
   float* gsr = (float*)AB(arena, P->off_gs);
-  float* bsums = gsr + (P->gs_floats - P->stats_floats);
+  float* bsums = gsr + (P->gs_floats - P->stats_floats * NUNET_BN_SUM_REPLICAS);
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
   bool (&written)[5][5] = rt_of(P)->bwd_written;
@@ -940,6 +940,10 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   auto cost_conv = [&](int lvl, double cin, double cout) { return (float)(9.0 + (lvl >= 3 ? 8.0 : 0.0) + 18.0 * cin * cout * (double)P->px[lvl] / conv_rate); };
   auto cost_wg = [&](int lvl, double cin, double cout) { return (float)(12.0 + 18.0 * cin * cout * (double)P->px[lvl] / wg_rate); };
   auto cost_mem = [&](double floor_us, double bytes) { return (float)(floor_us + bytes / 4.0e6); };
+  static int bnr_fuse_env = -1;
+  // measured: fusing takes 1 % off the summed kernel time but the step gets 0.5 % slower (schedule): off by default
+  if (bnr_fuse_env < 0) { const char* e = getenv("NUNET_BNR_FUSE"); bnr_fuse_env = e ? atoi(e) : 0; }
+  const bool bnr_fuse = bnr_fuse_env != 0;
   for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK && (phases & 1); ++k) {
     const Head& h = P->heads[k];
     const int acc = written[0][h.slot] ? 1 : 0;
@@ -972,13 +976,16 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       if (cv == 1) { b.da = AB(arena, P->GX[i] + (size_t)n.out_slot * f * es); b.PDA = P->PX[i]; b.y = AB(arena, n.y2); rda = R_GX + i * 5 + n.out_slot; ry = rb + B_Y2; }
       else { b.da = AB(arena, P->off_da1[k]); b.PDA = f; b.y = AB(arena, n.y1); rda = rl + L_DA1; ry = rb + B_Y1; }
       b.PY = f; b.mean_invstd = save + L.save; b.gamma = params + L.g_off; b.beta = params + L.be_off;
-      b.sums = bsums + L.bsum;
+      b.sums = bsums + L.bsum * NUNET_BN_SUM_REPLICAS;
       float* gl = gsr + L.gs + 9LL * L.cout * L.cinpad;
       b.dbias = gl; b.dgamma = gl + L.cout; b.dbeta = gl + 2 * L.cout;
       b.dy = dybuf; b.PDY = f;
       S.name("B%d%d.bnB%d", n.i, n.j, cv + 1);
-      S.add(lane, 0, cost_mem(12.0, 5.0 * (double)P->px[i] * f * es), {rda, ry}, {rdy, R_GSV + cidx}, [=](hipStream_t ls) {
-        int r = nunet_bn_relu_bwd_reduce(&b, ls);
+      // the reduce pass of the FIRST conv's BN is taken in the epilogue of the dgrad that produces its
+      // input gradient (conv3x3 BNR kernels): one launch and one read of da1 and y1 less per block
+      const bool fused_reduce = bnr_fuse && cv == 0;
+      S.add(lane, 0, cost_mem(fused_reduce ? 6.0 : 12.0, (fused_reduce ? 3.0 : 5.0) * (double)P->px[i] * f * es), {rda, ry}, {rdy, R_GSV + cidx}, [=](hipStream_t ls) {
+        int r = fused_reduce ? NUNET_OK : nunet_bn_relu_bwd_reduce(&b, ls);
         return r ? r : nunet_bn_relu_bwd_apply(&b, ls);
       });
       // weight gradient: a leaf of the dependency graph (only the final unpack reads it)
@@ -1004,7 +1011,12 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       S.name("B%d%d.dgrad%d", n.i, n.j, cv + 1);
       if (cv == 1) {
         d.dst0 = AB(arena, P->off_da1[k]); d.D0 = f; d.Q0 = f;
-        S.add(lane, 0, cost_conv(i, f, f), {rdy}, {rl + L_DA1, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
+        if (bnr_fuse) {
+          const ConvL& L1 = n.c1;
+          d.bn_y = AB(arena, n.y1); d.bn_py = f; d.bn_mean_invstd = save + L1.save;
+          d.bn_gamma = params + L1.g_off; d.bn_beta = params + L1.be_off; d.bn_sums = bsums + L1.bsum * NUNET_BN_SUM_REPLICAS;
+        }
+        S.add(lane, 0, cost_conv(i, f, f), {rdy, bnr_fuse ? rb + B_Y1 : -1}, {rl + L_DA1, rsk, bnr_fuse ? R_GSV + 2 * k : -1}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
       } else if (n.in_prefix == 0) {
         d.dst0 = AB(arena, P->off_gpin[k]); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1];
         S.add(lane, 0, cost_conv(i, f, NBF[i - 1]) + (i >= 3 ? 12.f : 0.f), {rdy}, {rl + L_GPIN, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });

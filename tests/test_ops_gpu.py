@@ -266,7 +266,7 @@ def test_bn_relu_bwd(dt):
     mi = torch.cat([mean, istd]).float().to(DEV)
     yb = nhwc(y, dt)
     dab = nhwc(da, dt, pitch=160, off=64)
-    sums = torch.zeros(2 * c, dtype=torch.float32, device=DEV)
+    sums = torch.zeros(L.BN_SUM_REPLICAS * 2 * c, dtype=torch.float32, device=DEV)
     dg = torch.zeros(c, dtype=torch.float32, device=DEV)
     db = torch.zeros(c, dtype=torch.float32, device=DEV)
     dbias = torch.zeros(c, dtype=torch.float32, device=DEV)
@@ -281,6 +281,51 @@ def test_bn_relu_bwd(dt):
     assert rel_err(dg.cpu(), gd.grad) < 1e-4 and rel_err(db.cpu(), bd.grad) < 1e-4
     # conv-bias gradient = sum of dy, analytically ~0; must be tiny relative to |dy| mass
     assert float(dbias.abs().max()) < 2e-2 * float(yd.grad.abs().sum((0, 2, 3)).max())
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
+@pytest.mark.parametrize("shape,sk", [((2, 20, 24, 32, 32), False), ((3, 12, 12, 64, 64), False), ((16, 6, 6, 512, 512), True)])
+def test_conv3x3_fused_bn_bwd_reduce(dt, shape, sk):
+    """The BatchNorm+ReLU backward reduce taken in the conv epilogue (plain and K-split finalize) equals
+    nunet_bn_relu_bwd_reduce run on the tensor the conv stored."""
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    y1 = q(torch.randn(n, cout, h, w, generator=g), dt)                 # raw output of the BN's conv
+    gamma = 1 + 0.2 * torch.randn(cout, generator=g)
+    beta = 0.2 * torch.randn(cout, generator=g)
+    mean = y1.double().mean((0, 2, 3))
+    istd = 1 / (y1.double().var((0, 2, 3), unbiased=False) + 1e-5).sqrt()
+    mi = torch.cat([mean, istd]).float().to(DEV)
+    s0 = nhwc(x, dt)
+    wf, _ = pack(wt, dt)
+    yb = nhwc(y1, dt)
+    out = torch.zeros((n, h, w, cout), dtype=tdt(dt), device=DEV)
+    sums = torch.zeros(L.BN_SUM_REPLICAS * 2 * cout, dtype=torch.float32, device=DEV)
+    gamma_g, beta_g = gamma.to(DEV), beta.to(DEV)
+    d = conv_desc(dt, n, h, w, s0, cin, cin, wf, out, cout, cout)
+    ws = None
+    if sk:
+        ws = torch.zeros(8 * n * h * w * cout, dtype=torch.float32, device=DEV)
+        d.splitk_ws = L.ptr(ws).value; d.splitk_ws_floats = ws.numel()
+    d.bn_y = L.ptr(yb).value; d.bn_py = cout; d.bn_mean_invstd = L.ptr(mi).value
+    d.bn_gamma = L.ptr(gamma_g).value; d.bn_beta = L.ptr(beta_g).value; d.bn_sums = L.ptr(sums).value
+    L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "conv+bnr")
+    ref_sums = torch.zeros_like(sums)
+    dummy = torch.zeros(cout, dtype=torch.float32, device=DEV)
+    dyb = torch.zeros_like(out)
+    b = L.BnBwdDesc(dt, n, h, w, cout, L.ptr(out), cout, L.ptr(yb), cout, L.ptr(mi), L.ptr(gamma_g), L.ptr(beta_g),
+                    L.ptr(ref_sums), L.ptr(dummy), L.ptr(dummy), L.ptr(dummy), L.ptr(dyb), cout)
+    L.check(L.lib().nunet_bn_relu_bwd_reduce(C.byref(b), L.stream()), "reduce")
+    torch.cuda.synchronize()
+    ref = F.conv2d(q(x, dt).double(), q(wt, dt).double(), padding=1)
+    assert rel_err(to_nchw(out, cout), ref) < TOL[dt]
+    assert float(ref_sums.abs().max()) > 0
+    tot = sums.view(L.BN_SUM_REPLICAS, 2 * cout).sum(0)
+    rtot = ref_sums.view(L.BN_SUM_REPLICAS, 2 * cout).sum(0)
+    scale = float(rtot.abs().max())
+    assert float((tot - rtot).abs().max()) < 2e-4 * scale + 1e-5, (DT[dt], shape)
 
 
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
