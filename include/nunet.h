@@ -68,7 +68,7 @@ typedef struct {
   int32_t acc_slot_w;               /* width (channels) of one dst0 slot, 0 = D0 */
   uint32_t acc0_mask;               /* bit k: dst0 slot k accumulates (+=) */
   int32_t acc1;                     /* dst1 accumulates */
-  float* stats;                     /* [2][Cout] fp32: += sum(y-b), sum((y-b)^2) or NULL */
+  float* stats;                     /* [NUNET_BN_SUM_REPLICAS][2][Cout] fp32, pre-zeroed: += sum(y-b), sum((y-b)^2); or NULL */
   float* splitk_ws;                 /* optional fp32 scratch: lets grid-starved layers split the contraction */
   int64_t splitk_ws_floats;         /* over workgroups (S slabs of N*H*W*Cout floats). NULL: never split */
   /* Optional fused BatchNorm+ReLU backward REDUCE (used for the dgrad of a block's second conv, whose
@@ -116,7 +116,7 @@ typedef struct {
   int32_t N, H, W, C;
   const void* y; int32_t PY;        /* conv output stored WITHOUT its bias */
   const float* conv_bias;           /* [C] or NULL: bias of the producing conv, folded in here */
-  const float* stats;               /* [2][C] sum / sum of squares of the stored y (training) */
+  const float* stats;               /* [NUNET_BN_SUM_REPLICAS][2][C] sums / sums of squares of the stored y (training) */
   const float* gamma; const float* beta;
   float* running_mean; float* running_var; int64_t* num_batches_tracked;
   float* save_mean_invstd;          /* [2][C] out (training): mean of the stored y, 1/sqrt(var+eps) */

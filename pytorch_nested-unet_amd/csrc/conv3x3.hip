@@ -497,8 +497,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int k = 0; k < WM; ++k) { s1 += s_red[(k * BN + c) * 2]; s2 += s_red[(k * BN + c) * 2 + 1]; }
-          atomicAdd(&p.stats[cur.co0 + c], s1);
-          atomicAdd(&p.stats[p.Cout + cur.co0 + c], s2);
+          float* const st = p.stats + (size_t)(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout;   // replica of this workgroup
+          atomicAdd(&st[cur.co0 + c], s1);
+          atomicAdd(&st[p.Cout + cur.co0 + c], s2);
         }
       }
       if (!have_next) break;
@@ -586,7 +587,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
   }
   if (p.stats) {
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x) atomicAdd(&p.stats[c], s_st[c]);
+    for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x)
+      atomicAdd(&p.stats[(size_t)(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout + c], s_st[c]);
   }
 }
 

@@ -136,8 +136,18 @@ struct BnFwdP {
 __device__ __forceinline__ void bn_channel_coeffs(const BnFwdP& p, int c, float M, float& mean, float& invstd, float& var, float& mean_full) {
   const float b = p.conv_bias ? p.conv_bias[c] : 0.f;
   if (p.training) {
-    mean = p.stats[c] / M;
-    var = fmaxf(p.stats[p.C + c] / M - mean * mean, 0.f);
+    float t1 = 0.f, t2 = 0.f;   // the producing conv adds to bn_sum_replicas(C) replicas (include/nunet.h)
+    const int nrep = bn_sum_replicas(p.C);
+    float q1[NUNET_BN_SUM_REPLICAS], q2[NUNET_BN_SUM_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) {   // all loads in flight at once
+      q1[r] = r < nrep ? p.stats[(r * 2 + 0) * p.C + c] : 0.f;
+      q2[r] = r < nrep ? p.stats[(r * 2 + 1) * p.C + c] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) { t1 += q1[r]; t2 += q2[r]; }
+    mean = t1 / M;
+    var = fmaxf(t2 / M - mean * mean, 0.f);
     mean_full = mean + b;
   } else {
     mean_full = p.rm[c];
@@ -338,7 +348,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
     if constexpr (APPLY) {
       float t1 = 0.f, t2 = 0.f;
       const int nrep = bn_sum_replicas(C);
-      for (int r = 0; r < nrep; ++r) { t1 += p.sums[(r * 2 + 0) * C + c]; t2 += p.sums[(r * 2 + 1) * C + c]; }
+      float q1[NUNET_BN_SUM_REPLICAS], q2[NUNET_BN_SUM_REPLICAS];
+#pragma unroll
+      for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) {   // all loads in flight at once
+        q1[r] = r < nrep ? p.sums[(r * 2 + 0) * C + c] : 0.f;
+        q2[r] = r < nrep ? p.sums[(r * 2 + 1) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) { t1 += q1[r]; t2 += q2[r]; }
       s_co[4 * C + c] = t1 / M; s_co[5 * C + c] = t2 / M;
     }
   }

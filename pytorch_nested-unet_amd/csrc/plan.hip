@@ -325,7 +325,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   // ---- arena ---------------------------------------------------------------------
   size_t cur = 0;
   P->stats_floats = (size_t)sv;
-  P->off_stats = bump(cur, P->stats_floats * 4);
+  P->off_stats = bump(cur, P->stats_floats * 4 * NUNET_BN_SUM_REPLICAS);   // replicated per-channel sums
   P->gs_floats = (size_t)gs + (size_t)sv * NUNET_BN_SUM_REPLICAS;  // grad scratch followed by the (replicated) bn-bwd sums
   P->off_gs = bump(cur, P->gs_floats * 4);
   P->off_save = bump(cur, (size_t)sv * 4);
@@ -779,7 +779,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
   // prerequisites of everything on the caller's stream, before the fork
-  if (training) CK(nunet_zero_async(stats, P->stats_floats * 4, st));
+  if (training) CK(nunet_zero_async(stats, P->stats_floats * 4 * NUNET_BN_SUM_REPLICAS, st));
   CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, s));
 
   Sched S; S.init(P, st, 0);
@@ -847,7 +847,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       d.wpack = wpack + (size_t)L.wf * es;
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
       d.dst0 = AB(arena, cv == 0 ? n.y1 : n.y2); d.D0 = f; d.Q0 = f;
-      d.stats = (training && !getenv("NUNET_DBG_NOSTATS")) ? stats + L.stats : nullptr;   // NUNET_DBG_NOSTATS: timing experiment only (wrong results)
+      d.stats = training ? stats + L.stats * NUNET_BN_SUM_REPLICAS : nullptr;
       if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
       g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
       rc = nunet_conv3x3_fwd(&d, ls);
@@ -857,7 +857,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
 
       nunet_bn_fwd_desc b; memset(&b, 0, sizeof(b));
       b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
-      b.y = d.dst0; b.PY = f; b.conv_bias = params + L.b_off; b.stats = stats + L.stats;
+      b.y = d.dst0; b.PY = f; b.conv_bias = params + L.b_off; b.stats = stats + L.stats * NUNET_BN_SUM_REPLICAS;
       b.gamma = params + L.g_off; b.beta = params + L.be_off;
       b.running_mean = bnbuf + L.rm_off; b.running_var = bnbuf + L.rv_off;
       b.num_batches_tracked = nbt ? nbt + L.bn_index : nullptr;

@@ -84,7 +84,7 @@ def test_conv3x3_fwd(dt, shape):
     s1 = nhwc(x[:, c0:], dt) if c1 else None
     wf, _ = pack(wt, dt)
     y = torch.full((n, h, w, cout), 7.0, dtype=tdt(dt), device=DEV)
-    stats = torch.zeros(2 * cout, dtype=torch.float32, device=DEV)
+    stats = torch.zeros(L.BN_SUM_REPLICAS * 2 * cout, dtype=torch.float32, device=DEV)
     bg = b.to(DEV)
     d = conv_desc(dt, n, h, w, s0, c0, c0 + 32, wf, y, cout, cout, src1=s1, c1=c1, p1=c1, bias=bg, stats=stats)
     L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "conv")
@@ -93,7 +93,7 @@ def test_conv3x3_fwd(dt, shape):
     assert rel_err(got, ref) < TOL[dt], (DT[dt], shape)
     # BN partial sums are taken about the bias on the rounded outputs
     dd = got.double() - b.double().view(1, -1, 1, 1)
-    s = stats.cpu().double()
+    s = stats.cpu().double().view(L.BN_SUM_REPLICAS, 2 * cout).sum(0)
     m = n * h * w
     np.testing.assert_allclose(s[:cout].numpy() / m, dd.sum((0, 2, 3)).numpy() / m, atol=1e-4 * float(dd.abs().max()) + 1e-6)
     np.testing.assert_allclose(s[cout:].numpy() / m, (dd * dd).sum((0, 2, 3)).numpy() / m, rtol=1e-3, atol=1e-6)
@@ -219,7 +219,9 @@ def test_bn_relu_fwd(dt, pool, training):
     rv = 0.5 + torch.rand(c, generator=g)
     yb = nhwc(ys, dt)
     dd = ys.double()
-    stats = torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3))]).float().to(DEV)
+    stats = torch.zeros(L.BN_SUM_REPLICAS * 2 * c, dtype=torch.float32)
+    stats[:2 * c] = torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3))]).float()     # replica 0 holds everything
+    stats = stats.to(DEV)
     a = torch.zeros((n, h, w, 160), dtype=tdt(dt), device=DEV)
     pooled = torch.zeros((n, h // 2, w // 2, c), dtype=tdt(dt), device=DEV) if pool else None
     rmg, rvg = rm.clone().to(DEV), rv.clone().to(DEV)
@@ -484,7 +486,7 @@ def test_conv3x3_splitk_slabs(dt):
     outs = []
     for accum in (0, 1, 0):
         y = nhwc(prev, dt)
-        stats = torch.zeros(2 * cout, dtype=torch.float32, device=DEV)
+        stats = torch.zeros(L.BN_SUM_REPLICAS * 2 * cout, dtype=torch.float32, device=DEV)
         d = conv_desc(dt, n, h, w, s0, c0, c0, wf, y, cout, cout, src1=s1, c1=c1, p1=c1, stats=stats,
                       slot_w=cout, mask=accum)
         d.splitk_ws = L.ptr(ws).value
@@ -496,7 +498,8 @@ def test_conv3x3_splitk_slabs(dt):
         if not accum:
             got = to_nchw(y, cout).double()
             m = n * h * w
-            np.testing.assert_allclose(stats[:cout].cpu().numpy() / m, got.sum((0, 2, 3)).numpy() / m, atol=1e-4)
+            tot = stats.view(L.BN_SUM_REPLICAS, 2 * cout).sum(0)
+            np.testing.assert_allclose(tot[:cout].cpu().numpy() / m, got.sum((0, 2, 3)).numpy() / m, atol=1e-4)
             outs.append(y.clone())
     assert torch.equal(outs[0], outs[1])
 

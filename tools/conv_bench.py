@@ -33,7 +33,7 @@ for name, H, c0, c1, cout in shapes:
     s1 = torch.randn(N, H, H, max(c1, 16), device=DEV).to(torch.bfloat16)
     w = (torch.randn(9 * cout * cin, device=DEV) * 0.05).to(torch.bfloat16)
     y = torch.zeros(N, H, H, cout, device=DEV, dtype=torch.bfloat16)
-    stats = torch.zeros(2 * cout, device=DEV)
+    stats = torch.zeros(8 * 2 * cout, device=DEV)
     dy = torch.randn(N, H, H, cout, device=DEV).to(torch.bfloat16)
     dw = torch.zeros(9 * cout * cin, device=DEV)
     gf = 2 * 9 * cin * cout * N * H * H / 1e9

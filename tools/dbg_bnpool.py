@@ -12,7 +12,7 @@ ys = T.q(torch.randn(n, c, h, w, generator=g) * 0.7, dt)
 gamma = 1 + 0.2 * torch.randn(c, generator=g); beta = 0.2 * torch.randn(c, generator=g)
 rm = 0.1 * torch.randn(c, generator=g); rv = 0.5 + torch.rand(c, generator=g)
 yb = T.nhwc(ys, dt); dd = ys.double()
-stats = torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3))]).float().to("cuda")
+stats = torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3)), torch.zeros(14 * c, dtype=torch.float64)]).float().to("cuda")
 a = torch.zeros((n, h, w, 160), dtype=T.tdt(dt), device="cuda")
 pooled = torch.zeros((n, h // 2, w // 2, c), dtype=T.tdt(dt), device="cuda")
 rmg, rvg = rm.clone().cuda(), rv.clone().cuda()
