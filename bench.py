@@ -167,10 +167,11 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             pat = {"conv3x3_fwd_dgrad<BM128,BN64>": "void conv3x3_kernel<", "conv3x3_fwd_dgrad<BM256,BN32>": "Li4ELi1ELi2ELi1ELb0",
-                   "conv3x3_wgrad(Cout>=64)": "wgrad_kernel", "conv3x3_wgrad(Cout=32)": "wgrad_kernel"}.get(top["name"])
+                   "conv3x3_wgrad(Cout>=64)": "wgrad_pair_kernel", "conv3x3_wgrad(Cout=32)": "wgrad_pair_kernel"}.get(top["name"])
             if pat and args.dtype == "bf16" and hw == 96 and n == 16:
                 for kname, rec in pmc.items():
-                    if pat in kname and "DF16b" in kname or (pat == "void conv3x3_kernel<" and kname.startswith(pat)):
+                    # (the BM128 class is the plain instantiation: neither K-split nor fused BN reduce)
+                    if pat in kname and "DF16b" in kname or (pat == "void conv3x3_kernel<" and kname.startswith(pat) and "false, false>" in kname):
                         roofline["traffic"] = rec["hbm_bytes_per_launch_corrected"]
                         roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                         roofline["algorithmic_bytes_per_launch"] = top["bytes"] / top["launches"]

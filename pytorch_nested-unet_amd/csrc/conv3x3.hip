@@ -937,7 +937,13 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = co0 + acc_row(i, h);
+#if defined(NUNET_ABL) && (NUNET_ABL & 256)
+        if (co < p.Cout) p.dw[((size_t)tap * p.Cout + co) * p.Cin + ci] = acc[t][i];    // timing experiment: no atomics
+#elif defined(NUNET_ABL) && (NUNET_ABL & 512)
+        if (co < p.Cout) atomicAdd(&p.dw[(size_t)(split & 7) * 9 * p.Cout * p.Cin + ((size_t)tap * p.Cout + co) * p.Cin + ci], acc[t][i]);   // timing experiment: 8 replicas (dw must be 8x)
+#else
         if (co < p.Cout) atomicAdd(&p.dw[((size_t)tap * p.Cout + co) * p.Cin + ci], acc[t][i]);
+#endif
       }
     }
   }
