@@ -52,6 +52,7 @@ const char* nunet_last_error(void);
  * the consumer sums those r replicas (replica stride 2*C floats). Same-address global atomics serialise at ~12 ns each on MI355X; 576 workgroups on one
  * address cost 7 us at the end of a 14 us kernel. */
 #define NUNET_BN_SUM_REPLICAS 8
+#define NUNET_SPLITK_COUNTER_FLOATS 256
 
 typedef struct {
   int32_t dtype;
@@ -69,8 +70,9 @@ typedef struct {
   uint32_t acc0_mask;               /* bit k: dst0 slot k accumulates (+=) */
   int32_t acc1;                     /* dst1 accumulates */
   float* stats;                     /* [NUNET_BN_SUM_REPLICAS][2][Cout] fp32, pre-zeroed: += sum(y-b), sum((y-b)^2); or NULL */
-  float* splitk_ws;                 /* optional fp32 scratch: lets grid-starved layers split the contraction */
-  int64_t splitk_ws_floats;         /* over workgroups (S slabs of N*H*W*Cout floats). NULL: never split */
+  float* splitk_ws;                 /* optional fp32 scratch: lets grid-starved layers split the contraction over */
+  int64_t splitk_ws_floats;         /* workgroups: NUNET_SPLITK_COUNTER_FLOATS arrival counters (ZERO before the first use;
+                                     * every launch leaves them zero) + S slabs of N*H*W*Cout floats. NULL: never split */
   /* Optional fused BatchNorm+ReLU backward REDUCE (used for the dgrad of a block's second conv, whose
    * output is the gradient entering the first conv's BN, archs1.py:18-19): with z = relu(bn(bn_y)),
    * dz = (z > 0) ? dst0 : 0, bn_sums[c] += sum dz, bn_sums[Cout + c] += sum dz * xhat. Needs D1 == 0,

@@ -87,6 +87,7 @@ struct ConvP {
   int SH;                // stacked-rows tiling: H + 1 (0 = off), see map_pixel
   int S, nch0, nch;      // K-split: slices, channel chunks of source 0 / total (SK kernels only)
   float* slabs;          // [S][pixels][Cout] fp32 partial sums
+  unsigned* sk_cnt;      // per (tile, Cout-tile) arrival counters (zero before and after every launch); NULL: separate finalize kernel
   long long slab_stride; // pixels * Cout
   // BNR kernels (dgrad of a block's second conv): the BatchNorm+ReLU backward REDUCE pass of the first
   // conv's BN is taken in the epilogue, on the values just stored (dst0 must be dense and assign-only)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   __shared__ int s_hidx[BM];         // tile-invariant: halo index of output row m
   __shared__ int s_mxy[BM];          // tile-invariant: packed (ni, ly, lx) of row m, -1 unused
   __shared__ int s_hxy[C::HPMAX];    // tile-invariant: packed (ni, hy, hx) of halo pixel, -1 unused
-  __shared__ int s_gpix[BM];         // per item: global pixel of row m, -1 masked
+  __shared__ int s_gpix[BM + 1];     // per item: global pixel of row m, -1 masked; [BM]: K-split "this slice arrived last" flag
   __shared__ float s_red[2 * WM * BN];
   __shared__ float s_bnc[BNR ? 4 * 512 : 1];   // BNR: [mean | invstd | scale | shift][Cout <= 512], loaded once
   T* const s_halo = s_buf;
@@ -353,6 +354,90 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
             const int gp = s_gpix[(wm * SM + a) * 32 + acc_row(i, h)];
             if (gp >= 0) slab[(size_t)gp * p.Cout + co] = acc[a][b][i];
             acc[a][b][i] = 0.f;
+          }
+        }
+      }
+      if constexpr (SK) {
+        if (p.sk_cnt) {
+          // ---- last arriver finalizes the tile (no separate finalize launch): every slice publishes its slab
+          // (device-scope fence), then counts itself in; the slice that completes the count sums the S slabs in
+          // fixed order (deterministic), adds the bias, converts, routes, and takes the BatchNorm statistics
+          __threadfence();
+          __syncthreads();
+          if (tid == 0) {
+            const int tix = item / p.S;
+            const unsigned old = atomicAdd(&p.sk_cnt[tix], 1u);
+            const bool last = old == (unsigned)(p.S - 1);
+            if (last) p.sk_cnt[tix] = 0u;             // all S arrivals are in: leave the counter clean for the next launch
+            s_gpix[BM] = last ? 1 : 0;
+          }
+          __syncthreads();
+          if (s_gpix[BM]) {
+            __threadfence();
+            constexpr int SEGS = BN / EPV;
+            float q1[EPV], q2[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { q1[e] = 0.f; q2[e] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < C::UO; ++k) {
+              const int u = tid + k * NT;
+              const int m = u / SEGS, seg = u - m * SEGS;
+              const int gp = m < BM ? s_gpix[m] : -1;
+              if (gp >= 0) {
+                const int co = cur.co0 + seg * EPV;
+                float x[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) x[e] = 0.f;
+                for (int sl = 0; sl < p.S; ++sl) {
+                  const f32x4* w4 = reinterpret_cast<const f32x4*>(p.slabs + (size_t)sl * p.slab_stride + (size_t)gp * p.Cout + co);
+#pragma unroll
+                  for (int v4 = 0; v4 < EPV / 4; ++v4) {
+                    const f32x4 t4 = w4[v4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[v4 * 4 + e] += t4[e];
+                  }
+                }
+                T* q; bool accum;
+                if (co < p.D0) { q = (T*)p.dst0 + (size_t)gp * p.Q0 + co; accum = (p.acc0_mask >> (p.slot_w > 0 ? co / p.slot_w : 0)) & 1u; }
+                else { q = (T*)p.dst1 + (size_t)gp * p.Q1 + (co - p.D0); accum = p.acc1 != 0; }
+                const Vec16<T> o = accum ? ld16(q) : zero16<T>();
+                Vec16<T> v;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                  const float bb = p.bias ? p.bias[co + e] : 0.f;
+                  float y = x[e] + bb;
+                  if (accum) y += o.get(e);
+                  v.set(e, y);
+                  const float d = to_f32(from_f32<T>(y)) - bb;
+                  q1[e] += d; q2[e] += d * d;
+                }
+                st16(q, v);
+              }
+            }
+            if (p.stats) {
+#pragma unroll
+              for (int off = SEGS; off < 64; off <<= 1) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) { q1[e] += __shfl_xor(q1[e], off); q2[e] += __shfl_xor(q2[e], off); }
+              }
+              float* s_fin = reinterpret_cast<float*>(s_buf);     // [waves][2][BN]; the staging arena is idle here
+              if (lane < SEGS) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                  s_fin[(wave * 2 + 0) * BN + lane * EPV + e] = q1[e];
+                  s_fin[(wave * 2 + 1) * BN + lane * EPV + e] = q2[e];
+                }
+              }
+              __syncthreads();
+              float* const stp = p.stats + (size_t)(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout;
+              for (int t = tid; t < 2 * BN; t += NT) {
+                const int vsel = t / BN, c = t - vsel * BN;
+                float sum = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < WM * WN; ++wv) sum += s_fin[(wv * 2 + vsel) * BN + c];
+                atomicAdd(&stp[vsel * p.Cout + cur.co0 + c], sum);
+              }
+            }
           }
         }
       }
@@ -651,17 +736,23 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   long items = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
   // K-split for the grid-starved deep levels: slices of the channel-chunk loop become extra items, each
   // writes an fp32 partial slab; splitk_finalize_kernel sums them (fixed order, deterministic)
-  p.S = 1; p.slabs = nullptr; p.slab_stride = 0;
+  p.S = 1; p.slabs = nullptr; p.slab_stride = 0; p.sk_cnt = nullptr;
   p.nch0 = ceil_div(p.C0, C::KC);
   p.nch = p.nch0 + (p.C1 > 0 ? ceil_div(p.C1, C::KC) : 0);
   static int sk_max_items = -1;
   if (sk_max_items < 0) { const char* e = getenv("NUNET_SK_MAXITEMS"); sk_max_items = e ? atoi(e) : 100; }
-  if (d->splitk_ws && items <= sk_max_items && p.nch >= 8 && p.Cout <= 1024) {
+  // the first NUNET_SPLITK_COUNTER_FLOATS floats of the workspace are the arrival counters of the in-kernel
+  // finalize (zero before the first use, left zero by every launch); the slabs follow
+  static int sk_inkernel = -1;
+  if (sk_inkernel < 0) { const char* e = getenv("NUNET_SK_INKERNEL"); sk_inkernel = e ? atoi(e) : 0;   /* measured: the device-scope fences (L2 write-back + invalidate on every workgroup) cost 470 us per step: off */ }
+  if (d->splitk_ws && d->splitk_ws_floats > NUNET_SPLITK_COUNTER_FLOATS && items <= sk_max_items && p.nch >= 8 && p.Cout <= 1024) {
     int S = (int)((320 + items - 1) / items);
     if (S > p.nch / 2) S = p.nch / 2;
     const long long need = (long long)S * d->N * d->H * d->W * p.Cout;
-    if (S > 1 && need <= d->splitk_ws_floats) {
-      p.S = S; p.slabs = d->splitk_ws; p.slab_stride = (long long)d->N * d->H * d->W * p.Cout; items *= S;
+    if (S > 1 && need <= d->splitk_ws_floats - NUNET_SPLITK_COUNTER_FLOATS) {
+      p.S = S; p.slabs = d->splitk_ws + NUNET_SPLITK_COUNTER_FLOATS; p.slab_stride = (long long)d->N * d->H * d->W * p.Cout;
+      if (sk_inkernel && !bnr && items <= NUNET_SPLITK_COUNTER_FLOATS) p.sk_cnt = reinterpret_cast<unsigned*>(d->splitk_ws);
+      items *= S;
     }
   }
   p.nItems = (int)items;
@@ -679,6 +770,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
                (px * (acin + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
   if (p.S > 1) {
     hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+    if (p.sk_cnt) return nunet_check_launch("conv3x3 (K-split, in-kernel finalize)");
     SplitFinP f;
     f.slabs = p.slabs; f.slab_stride = p.slab_stride; f.S = p.S; f.bias = p.bias;
     f.dst0 = p.dst0; f.dst1 = p.dst1; f.D0 = p.D0; f.D1 = p.D1; f.Q0 = p.Q0; f.Q1 = p.Q1;

@@ -186,6 +186,7 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   std::vector<hipStream_t> cap_streams;   // never-reused streams for capture-time lane continuation
   size_t cap_next;
   void* gs_clean_arena;
+  void* sk_ready_arena;                    // arena whose K-split arrival counters have been zeroed
   bool bwd_written[5][5]; int bwd_pp[5];   // state carried between backward phases   // arena whose gradient scratch was cleared by the last training forward
   // NUNET_STAMPS=1 diagnostic: a 1-thread kernel after every scheduled op writes the 100 MHz wall clock,
   // so the real timeline of an (unprofiled) hipGraph replay can be read back (tools/stamp_timeline.py)
@@ -357,7 +358,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   const bool sk_on = !ske || atoi(ske) != 0;
   for (int i = 0; i < 5; ++i) {
     const int maxc = (i < 3 || !sk_on) ? 0 : (i < 4 ? (4 - i) * NBF[i] + NBF[i + 1] : NBF[4]);
-    P->sk_floats[i] = 8LL * P->px[i] * maxc;
+    P->sk_floats[i] = 8LL * P->px[i] * maxc + NUNET_SPLITK_COUNTER_FLOATS;   // arrival counters + up to 8 slabs
     P->off_sk[i] = bump(cur, (size_t)P->sk_floats[i] * 4 + 16);
   }
   P->total = align_up(cur, 256);
@@ -394,6 +395,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->lanes_external = false;
   rt->cap_next = 0;
   rt->gs_clean_arena = nullptr;
+  rt->sk_ready_arena = nullptr;
   rt->stamps = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
   { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
@@ -780,6 +782,11 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   char* wpack = AB(arena, P->off_wpack);
   // prerequisites of everything on the caller's stream, before the fork
   if (training) CK(nunet_zero_async(stats, P->stats_floats * 4 * NUNET_BN_SUM_REPLICAS, st));
+  if (rt_of(P)->sk_ready_arena != arena) {   // K-split arrival counters: zero once, every launch leaves them zero
+    for (int l = 0; l < 5; ++l)
+      if (P->sk_floats[l] > 0) CK(nunet_zero_async(AB(arena, P->off_sk[l]), NUNET_SPLITK_COUNTER_FLOATS * 4, st));
+    rt_of(P)->sk_ready_arena = arena;
+  }
   CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, s));
 
   Sched S; S.init(P, st, 0);
@@ -799,7 +806,9 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   }
   for (int l = 0; l < 5 && rc == NUNET_OK && pack_lanes; ++l) {
     if (P->ptab_lvl[l].n == 0) continue;
-    hipStream_t ls = S.begin(l, {}, {R_WP + l});
+    // 1: each level on its own lane; 2: level 0 on the chain lane (needed first), the rest one after the other on lane 3
+    S.name("pack%d", l);
+    hipStream_t ls = S.begin(pack_lanes == 2 ? (l == 0 ? 0 : 3) : l, {}, {R_WP + l});
     if (dt == NUNET_F32) rc = launch_pack<float>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);
     else if (dt == NUNET_BF16) rc = launch_pack<bf16_t>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);
     else rc = launch_pack<f16_t>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);

@@ -309,7 +309,7 @@ def test_conv3x3_fused_bn_bwd_reduce(dt, shape, sk):
     d = conv_desc(dt, n, h, w, s0, cin, cin, wf, out, cout, cout)
     ws = None
     if sk:
-        ws = torch.zeros(8 * n * h * w * cout, dtype=torch.float32, device=DEV)
+        ws = torch.zeros(8 * n * h * w * cout + 256, dtype=torch.float32, device=DEV)
         d.splitk_ws = L.ptr(ws).value; d.splitk_ws_floats = ws.numel()
     d.bn_y = L.ptr(yb).value; d.bn_py = cout; d.bn_mean_invstd = L.ptr(mi).value
     d.bn_gamma = L.ptr(gamma_g).value; d.bn_beta = L.ptr(beta_g).value; d.bn_sums = L.ptr(sums).value
@@ -482,7 +482,8 @@ def test_conv3x3_splitk_slabs(dt):
     prev = torch.randn(n, cout, h, w, generator=g)
     s0, s1 = nhwc(x[:, :c0], dt), nhwc(x[:, c0:], dt)
     wf, _ = pack(wt, dt)
-    ws = torch.full((8 * n * h * w * cout + 4,), 7.0, dtype=torch.float32, device=DEV)   # garbage: slabs are fully overwritten
+    ws = torch.full((8 * n * h * w * cout + 256,), 7.0, dtype=torch.float32, device=DEV)   # garbage: slabs are fully overwritten
+    ws[:256] = 0                                                                           # ... but the arrival counters start at zero
     outs = []
     for accum in (0, 1, 0):
         y = nhwc(prev, dt)
@@ -490,7 +491,7 @@ def test_conv3x3_splitk_slabs(dt):
         d = conv_desc(dt, n, h, w, s0, c0, c0, wf, y, cout, cout, src1=s1, c1=c1, p1=c1, stats=stats,
                       slot_w=cout, mask=accum)
         d.splitk_ws = L.ptr(ws).value
-        d.splitk_ws_floats = 8 * n * h * w * cout
+        d.splitk_ws_floats = ws.numel()
         L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "conv splitk")
         ref = F.conv2d(q(x, dt).double(), q(wt, dt).double(), None, padding=1)
         exp = ref + (q(prev, dt).double() if accum else 0)

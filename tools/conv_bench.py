@@ -42,8 +42,8 @@ for name, H, c0, c1, cout in shapes:
         d = L.ConvDesc(dt, N, H, H, L.ptr(s0), c0, c0 + 32, L.ptr(s1) if c1 else None, c1, max(c1, 16), L.ptr(w), None,
                        L.ptr(y), cout, cout, None, 0, 0, 0, 0, 0, L.ptr(stats))
         if os.environ.get("SK"):
-            ws = torch.zeros(8 * N * H * H * cout + 4, device=DEV)
-            d.splitk_ws = L.ptr(ws).value; d.splitk_ws_floats = 8 * N * H * H * cout
+            ws = torch.zeros(8 * N * H * H * cout + 256, device=DEV)
+            d.splitk_ws = L.ptr(ws).value; d.splitk_ws_floats = ws.numel()
         fn = lambda: L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()))
     else:
         d = L.WgradDesc(dt, N, H, H, L.ptr(s0), c0, c0 + 32, L.ptr(s1) if c1 else None, c1, max(c1, 16), L.ptr(dy), cout, cout, L.ptr(dw))
