@@ -196,9 +196,10 @@ int nunet_loss_step(const float* logits, const float* target, int32_t N, int64_t
                     int32_t heads, float* ws, float* dlogits, float* loss_out, double* meters,
                     nunet_stream_t s);
 /* LovaszHingeLoss (losses.py:49-96,120-129; per_image=True, mean over images). logits/target: [N][per_image]
- * (num_classes must be 1: the reference squeezes dim 1). Per-image sort in LDS: per_image <= 16384.
+ * (num_classes must be 1: the reference squeezes dim 1). Per-image sort: in LDS up to 16384 pixels, chunk sorts +
+ * global bitonic merge passes above (up to 2^22); ws of nunet_lovasz_ws_bytes(N, per_image) bytes, 256-byte aligned.
  * dlogits_unit receives d loss / d logits for an upstream gradient of 1; _bwd scales it by gscale[0]. */
-size_t nunet_lovasz_ws_bytes(int32_t N);
+size_t nunet_lovasz_ws_bytes(int32_t N, int64_t per_image);
 int nunet_lovasz_hinge_fwd(const float* logits, const float* target, int32_t N, int64_t per_image,
                            float* ws, float* dlogits_unit, float* loss, nunet_stream_t s);
 int nunet_lovasz_hinge_bwd(const float* dlogits_unit, const float* gscale, int64_t n, float* dlogits,
@@ -206,6 +207,8 @@ int nunet_lovasz_hinge_bwd(const float* dlogits_unit, const float* gscale, int64
 /* counts[0] += |A&B|, counts[1] += |A|B|, A = logits>0, B = target>0.5 */
 int nunet_iou_counts(const float* logits, const float* target, int64_t n,
                      unsigned long long* counts, nunet_stream_t s);
+/* Mask export of the evaluation driver (reference val.py:100-105): out[i] = uint8(sigmoid(logits[i]) * 255). */
+int nunet_sigmoid_u8(const float* logits, uint8_t* out, int64_t n, nunet_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* optim.SGD.step as configured at trains.py:229-231                         */

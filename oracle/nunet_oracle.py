@@ -259,3 +259,27 @@ def upsample2x_bilinear_ac_np(x):
     top = xd[:, :, y0][:, :, :, x0] * (1 - fx) + xd[:, :, y0][:, :, :, x1] * fx
     bot = xd[:, :, y1][:, :, :, x0] * (1 - fx) + xd[:, :, y1][:, :, :, x1] * fx
     return top * (1 - fy)[None, None, :, None] + bot * fy[None, None, :, None]
+
+
+# ---------------------------------------------------------------------------
+# Lovasz hinge (reference losses.py:49-61 lovasz_grad, :64-96 lovasz_hinge / _flat, :120-129 LovaszHingeLoss:
+# per_image=True, mean over images, channel dim squeezed)
+# ---------------------------------------------------------------------------
+
+def lovasz_hinge(logits, labels):
+    """logits, labels: torch [N, H, W] (any float dtype). Differentiable restatement with torch ops only."""
+    losses = []
+    for lg, lb in zip(logits, labels):
+        lg, lb = lg.reshape(-1), lb.reshape(-1)
+        signs = 2.0 * lb - 1.0
+        errors = 1.0 - lg * signs
+        errors_sorted, perm = torch.sort(errors, dim=0, descending=True)
+        gt_sorted = lb[perm]
+        gts = gt_sorted.sum()
+        intersection = gts - gt_sorted.cumsum(0)
+        union = gts + (1.0 - gt_sorted).cumsum(0)
+        jaccard = 1.0 - intersection / union
+        if gt_sorted.numel() > 1:
+            jaccard = torch.cat([jaccard[:1], jaccard[1:] - jaccard[:-1]])
+        losses.append(torch.dot(torch.relu(errors_sorted), jaccard.detach()))
+    return sum(losses) / len(losses)

@@ -94,10 +94,11 @@ _SIG = {
     "nunet_bce_dice_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
     "nunet_loss_step_ws_bytes": (C.c_size_t, [_i32, _i32]),
     "nunet_loss_step": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "nunet_lovasz_ws_bytes": (C.c_size_t, [_i32]),
+    "nunet_lovasz_ws_bytes": (C.c_size_t, [_i32, _i64]),
     "nunet_lovasz_hinge_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
     "nunet_lovasz_hinge_bwd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "nunet_iou_counts": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "nunet_sigmoid_u8": (_i32, [_vp, _vp, _i64, _vp]),
     "nunet_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _i32, _f32, _vp]),
     "nunet_preprocess_u8": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
     "nunet_nchw_to_nhwc": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

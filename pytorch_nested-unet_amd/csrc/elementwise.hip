@@ -984,6 +984,34 @@ extern "C" int nunet_iou_counts(const float* logits, const float* target, int64_
 }
 
 // ---------------------------------------------------------------------------
+// Mask export of the evaluation driver: uint8(sigmoid(logit) * 255), truncating like numpy's astype('uint8')
+// (reference val.py:100-105: `(output[i, c] * 255).astype('uint8')` after torch.sigmoid)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sigmoid_u8_kernel(const float* __restrict__ logits, uint8_t* __restrict__ out, int64_t n) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(logits)[i];
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pr = 1.0f / (1.0f + expf(-v[e]));
+      w |= (uint32_t)(uint8_t)(pr * 255.0f) << (8 * e);
+    }
+    reinterpret_cast<uint32_t*>(out)[i] = w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    out[i] = (uint8_t)(255.0f / (1.0f + expf(-logits[i])));
+  }
+}
+extern "C" int nunet_sigmoid_u8(const float* logits, uint8_t* out, int64_t n, nunet_stream_t s) {
+  NUNET_REQUIRE(logits && out && n > 0, "sigmoid_u8: bad args");
+  NUNET_REQUIRE(((uintptr_t)logits & 15) == 0 && ((uintptr_t)out & 3) == 0, "sigmoid_u8: logits must be 16-byte and out 4-byte aligned");
+  hipLaunchKernelGGL(sigmoid_u8_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)s, logits, out, n);
+  return nunet_check_launch("sigmoid_u8");
+}
+
+// ---------------------------------------------------------------------------
 // SGD with momentum / weight decay / nesterov (torch.optim.SGD semantics)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, int64_t n, const float* __restrict__ lr_dev, float mom, float wd, int nesterov, int first, float gscale) {

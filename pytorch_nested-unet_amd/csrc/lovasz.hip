@@ -3,7 +3,9 @@
 // 64-bit (sortable key | pixel index | label) words in LDS, inclusive scan of the sorted labels,
 // Jaccard increments (lovasz_grad, losses.py:49-61), loss = sum relu(e_k) * g_k and the
 // sub-gradient d loss / d x[perm_k] = -(2t-1) * g_k * [e_k > 0] written in the same pass.
-// Limit this round: pixels per image <= 16384 (128 KiB of LDS); larger images are refused.
+// Images of up to 16384 pixels sort in LDS in that one kernel; larger ones (256x256, 512x512: BASELINE cfg4/cfg5
+// geometries) go through the global-memory pipeline at the end of this file (chunk sorts in LDS + global bitonic
+// merge passes + chunked scan), up to 2^22 pixels per image.
 #include "common.h"
 
 #define LOVASZ_NMAX 16384
@@ -114,27 +116,191 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ a,
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = a[i] * s;
 }
 
-extern "C" size_t nunet_lovasz_ws_bytes(int32_t N) { return (size_t)N * sizeof(float); }
+// ---------------------------------------------------------------------------------------------------------
+// Large images: keys in global memory. key = [63:32] sortable error | [31:1] pixel index | [0] label
+// (padding = 0 sorts last in descending order). Bitonic network over NP2 = 2^m keys per image:
+//   stages k <= CHUNK entirely in LDS per 16384-key chunk (lv_local_kernel, first = true),
+//   stage k > CHUNK: steps j >= CHUNK as global compare-exchange passes (lv_global_kernel), the remaining
+//   steps j < CHUNK again in LDS per chunk (lv_local_kernel, first = false).
+// Then labels are summed per chunk (lv_chunksum_kernel) and lv_final_kernel walks each chunk with its prefix.
+// ---------------------------------------------------------------------------------------------------------
+#define LV_CHUNK 16384
+
+__global__ __launch_bounds__(256) void lv_keys_kernel(const float* __restrict__ x, const float* __restrict__ t, int P, int NP2, unsigned long long* __restrict__ keys) {
+  const int img = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NP2; i += gridDim.x * blockDim.x) {
+    unsigned long long w = 0ull;
+    if (i < P) {
+      const float lab = t[(size_t)img * P + i];
+      const float e = 1.f - x[(size_t)img * P + i] * (2.f * lab - 1.f);
+      w = ((unsigned long long)f32_sortable(e) << 32) | ((unsigned long long)i << 1) | (lab > 0.5f ? 1ull : 0ull);
+    }
+    keys[(size_t)img * NP2 + i] = w;
+  }
+}
+
+// one workgroup per (chunk, image); `first`: all stages k = 2..CHUNK; else: the steps j = CHUNK/2..1 of stage k
+__global__ __launch_bounds__(LOVASZ_NT) void lv_local_kernel(unsigned long long* __restrict__ keys, int NP2, int first, int kstage) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_k[];   // LV_CHUNK words
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * LV_CHUNK;                                    // global index of the chunk's first key
+  unsigned long long* g = keys + (size_t)blockIdx.y * NP2 + base;
+  for (int i = tid; i < LV_CHUNK; i += LOVASZ_NT) s_k[i] = g[i];
+  __syncthreads();
+  for (int k = first ? 2 : kstage; k <= (first ? LV_CHUNK : kstage); k <<= 1) {
+    for (int j = (k >> 1) < LV_CHUNK ? (k >> 1) : (LV_CHUNK >> 1); j > 0; j >>= 1) {
+      for (int q = tid; q < LV_CHUNK / 2; q += LOVASZ_NT) {
+        const int i = 2 * q - (q & (j - 1));
+        const int p2 = i + j;
+        const unsigned long long a = s_k[i], b = s_k[p2];
+        const bool desc = ((base + i) & k) == 0;
+        if (desc ? (a < b) : (a > b)) { s_k[i] = b; s_k[p2] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < LV_CHUNK; i += LOVASZ_NT) g[i] = s_k[i];
+}
+
+// step (k, j) with j >= LV_CHUNK: partners live in different chunks
+__global__ __launch_bounds__(256) void lv_global_kernel(unsigned long long* __restrict__ keys, int NP2, int k, int j) {
+  unsigned long long* g = keys + (size_t)blockIdx.y * NP2;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < NP2 / 2; q += gridDim.x * blockDim.x) {
+    const int i = 2 * q - (q & (j - 1));
+    const int p2 = i + j;
+    const unsigned long long a = g[i], b = g[p2];
+    const bool desc = (i & k) == 0;
+    if (desc ? (a < b) : (a > b)) { g[i] = b; g[p2] = a; }
+  }
+}
+
+__global__ __launch_bounds__(LOVASZ_NT) void lv_chunksum_kernel(const unsigned long long* __restrict__ keys, int NP2, float* __restrict__ csum) {
+  __shared__ float s_red[LOVASZ_NT / 64];
+  const unsigned long long* g = keys + (size_t)blockIdx.y * NP2 + (size_t)blockIdx.x * LV_CHUNK;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < LV_CHUNK; i += LOVASZ_NT) acc += (float)(g[i] & 1ull);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int q = 0; q < LOVASZ_NT / 64; ++q) s += s_red[q];
+    csum[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// Jaccard increments, loss partial and sub-gradient of one chunk (losses.py:49-61,64-96)
+__global__ __launch_bounds__(LOVASZ_NT) void lv_final_kernel(const unsigned long long* __restrict__ keys, int P, int NP2, const float* __restrict__ csum,
+                                                            float* __restrict__ dx, float* __restrict__ part, float inv_batch) {
+  __shared__ float s_part[LOVASZ_NT];
+  __shared__ float s_red[LOVASZ_NT / 64];
+  const int tid = threadIdx.x, img = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+  const unsigned long long* g = keys + (size_t)img * NP2 + (size_t)chunk * LV_CHUNK;
+  float before = 0.f, gts = 0.f;
+  for (int c = 0; c < nch; ++c) { const float v = csum[img * nch + c]; gts += v; if (c < chunk) before += v; }
+  constexpr int per = LV_CHUNK / LOVASZ_NT;
+  const int lo = tid * per;
+  unsigned long long w[per];
+  float run = 0.f;
+#pragma unroll
+  for (int q = 0; q < per; ++q) { w[q] = g[lo + q]; run += (float)(w[q] & 1ull); }
+  s_part[tid] = run;
+  __syncthreads();
+  for (int off = 1; off < LOVASZ_NT; off <<= 1) {
+    const float v = tid >= off ? s_part[tid - off] : 0.f;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  float cum = before + s_part[tid] - run;            // labels before this thread's run (whole image)
+  const long long gi0 = (long long)chunk * LV_CHUNK + lo;   // index of the run's first element in the sorted image
+  float jprev = 0.f;
+  if (gi0 > 0) { const float inter = gts - cum, uni = gts + ((float)gi0 - cum); jprev = 1.f - inter / uni; }
+  float acc = 0.f;
+  float* ds = dx + (size_t)img * P;
+#pragma unroll
+  for (int q = 0; q < per; ++q) {
+    const long long gi = gi0 + q;
+    const float lab = (float)(w[q] & 1ull);
+    cum += lab;
+    const float inter = gts - cum, uni = gts + ((float)(gi + 1) - cum);
+    const float jac = 1.f - inter / uni;
+    const float gk = gi == 0 ? jac : jac - jprev;
+    jprev = jac;
+    if (w[q] != 0ull) {
+      const int idx = (int)((w[q] >> 1) & 0x7FFFFFFFull);
+      const float e = sortable_f32((uint32_t)(w[q] >> 32));
+      const bool on = e > 0.f;
+      if (on) acc += e * gk;
+      ds[idx] = on ? -(2.f * lab - 1.f) * gk * inv_batch : 0.f;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int q = 0; q < LOVASZ_NT / 64; ++q) s += s_red[q];
+    part[img * nch + chunk] = s;
+  }
+}
+
+__global__ void lv_mean_kernel(const float* __restrict__ part, int total, int N, float* __restrict__ loss) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < total; i += 64) s += part[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) loss[0] = s / (float)N;
+}
+
+static int lovasz_np2(int64_t per_image) {
+  int np2 = 1;
+  while (np2 < per_image) np2 <<= 1;
+  return np2;
+}
+// workspace: per-image losses; for images above the LDS limit also the keys, chunk sums and chunk partials
+extern "C" size_t nunet_lovasz_ws_bytes(int32_t N, int64_t per_image) {
+  if (per_image <= LOVASZ_NMAX) return (size_t)N * sizeof(float);
+  const size_t np2 = (size_t)lovasz_np2(per_image), nch = np2 / LV_CHUNK;
+  return (size_t)N * np2 * 8 + 2 * (size_t)N * nch * sizeof(float) + 256;
+}
 
 // loss = mean over images of the Lovasz hinge; dlogits_unit = d loss / d logits (for an upstream gradient of 1)
 extern "C" int nunet_lovasz_hinge_fwd(const float* logits, const float* target, int32_t N, int64_t per_image,
                                       float* ws, float* dlogits_unit, float* loss, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && dlogits_unit && loss && N > 0 && per_image > 0, "lovasz_hinge_fwd: bad args");
-  NUNET_REQUIRE(per_image <= LOVASZ_NMAX, "lovasz_hinge_fwd: %lld pixels per image exceed the in-LDS sort limit of %d", (long long)per_image, LOVASZ_NMAX);
-  int np2 = 1;
-  while (np2 < per_image) np2 <<= 1;
-  if (np2 < 2 * LOVASZ_NT) np2 = 2 * LOVASZ_NT;      // every thread owns at least one compare pair / scan run
+  NUNET_REQUIRE(per_image <= (1LL << 22), "lovasz_hinge_fwd: %lld pixels per image exceed the limit of 2^22", (long long)per_image);
   hipStream_t st = (hipStream_t)s;
-  const size_t lds = (size_t)np2 * 8;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)lovasz_hinge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LOVASZ_NMAX * 8);
+    (void)hipFuncSetAttribute((const void*)lv_local_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LV_CHUNK * 8);
     attr_set = true;
   }
   ProfScope ps(PC_LOSS, 0, (double)N * per_image * 12, st);
-  hipLaunchKernelGGL(lovasz_hinge_kernel, dim3(N), dim3(LOVASZ_NT), lds, st, logits, target, (int)per_image, np2, dlogits_unit, ws, 1.f / (float)N);
-  hipLaunchKernelGGL(lovasz_mean_kernel, dim3(1), dim3(64), 0, st, ws, N, loss);
-  return nunet_check_launch("lovasz_hinge_fwd");
+  if (per_image <= LOVASZ_NMAX) {
+    int np2 = lovasz_np2(per_image);
+    if (np2 < 2 * LOVASZ_NT) np2 = 2 * LOVASZ_NT;      // every thread owns at least one compare pair / scan run
+    const size_t lds = (size_t)np2 * 8;
+    hipLaunchKernelGGL(lovasz_hinge_kernel, dim3(N), dim3(LOVASZ_NT), lds, st, logits, target, (int)per_image, np2, dlogits_unit, ws, 1.f / (float)N);
+    hipLaunchKernelGGL(lovasz_mean_kernel, dim3(1), dim3(64), 0, st, ws, N, loss);
+    return nunet_check_launch("lovasz_hinge_fwd");
+  }
+  const int np2 = lovasz_np2(per_image), nch = np2 / LV_CHUNK;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws);
+  float* csum = reinterpret_cast<float*>(keys + (size_t)N * np2);
+  float* part = csum + (size_t)N * nch;
+  const unsigned gx = (unsigned)((np2 / 2 + 255) / 256 > 1024 ? 1024 : (np2 / 2 + 255) / 256);
+  hipLaunchKernelGGL(lv_keys_kernel, dim3(gx, N), dim3(256), 0, st, logits, target, (int)per_image, np2, keys);
+  hipLaunchKernelGGL(lv_local_kernel, dim3(nch, N), dim3(LOVASZ_NT), LV_CHUNK * 8, st, keys, np2, 1, 0);
+  for (int k = 2 * LV_CHUNK; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j >= LV_CHUNK; j >>= 1)
+      hipLaunchKernelGGL(lv_global_kernel, dim3(gx, N), dim3(256), 0, st, keys, np2, k, j);
+    hipLaunchKernelGGL(lv_local_kernel, dim3(nch, N), dim3(LOVASZ_NT), LV_CHUNK * 8, st, keys, np2, 0, k);
+  }
+  hipLaunchKernelGGL(lv_chunksum_kernel, dim3(nch, N), dim3(LOVASZ_NT), 0, st, keys, np2, csum);
+  hipLaunchKernelGGL(lv_final_kernel, dim3(nch, N), dim3(LOVASZ_NT), 0, st, keys, (int)per_image, np2, csum, dlogits_unit, part, 1.f / (float)N);
+  hipLaunchKernelGGL(lv_mean_kernel, dim3(1), dim3(64), 0, st, part, N * nch, N, loss);
+  return nunet_check_launch("lovasz_hinge_fwd (global sort)");
 }
 extern "C" int nunet_lovasz_hinge_bwd(const float* dlogits_unit, const float* gscale, int64_t n, float* dlogits, nunet_stream_t s) {
   NUNET_REQUIRE(dlogits_unit && dlogits && n > 0, "lovasz_hinge_bwd: bad args");

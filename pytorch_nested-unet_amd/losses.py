@@ -55,7 +55,7 @@ class _LovaszFn(torch.autograd.Function):
                                % (tuple(logits.shape), tuple(target.shape)))
         n = logits.size(0)
         per = logits.numel() // n
-        ws = torch.empty(n, dtype=torch.float32, device=logits.device)
+        ws = torch.empty(L.lib().nunet_lovasz_ws_bytes(n, per), dtype=torch.uint8, device=logits.device)
         unit = torch.empty_like(logits)
         loss = torch.empty(1, dtype=torch.float32, device=logits.device)
         L.check(L.lib().nunet_lovasz_hinge_fwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.ptr(unit), L.ptr(loss),

@@ -26,3 +26,16 @@ def iou_score(output, target):
     """Same value and return type (python float) as reference metrics.py:6-18;
     like the reference it synchronises with the device."""
     return iou_from_counts(iou_counts(output.detach().contiguous(), target.contiguous()))
+
+
+def sigmoid_masks_u8(output):
+    """uint8 masks of the evaluation driver, `(sigmoid(output) * 255).astype('uint8')` (reference val.py:100-105),
+    computed on the device: [N, K, H, W] fp32 logits -> [N, K, H, W] uint8."""
+    import torch
+    from . import _lib as L
+    out = output.detach().contiguous()
+    if out.dtype != torch.float32 or not out.is_cuda:
+        raise L.NunetError("sigmoid_masks_u8: CUDA fp32 logits expected")
+    m = torch.empty(out.shape, dtype=torch.uint8, device=out.device)
+    L.check(L.lib().nunet_sigmoid_u8(L.ptr(out), L.ptr(m), out.numel(), L.stream()), "sigmoid_u8")
+    return m

@@ -517,8 +517,30 @@ def test_lovasz_hinge_against_reference_goldens():
         (loss * 0.5).backward()
         assert abs(float(loss.detach()) - float(g["loss_" + tag])) < 2e-5 * max(1.0, float(g["loss_" + tag])), tag
         np.testing.assert_allclose(x.grad.cpu().numpy() * 2, g["dx_" + tag], atol=2e-7, rtol=2e-4, err_msg=tag)
+
+
+@pytest.mark.parametrize("shape", [(2, 144, 160), (3, 256, 256), (1, 512, 512)])
+def test_lovasz_hinge_large_images_match_oracle(shape):
+    """Images above the in-LDS sort limit (16384 px): chunk sorts + global bitonic merge passes + chunked scan,
+    against the oracle's restatement (itself pinned to the reference goldens in tests/test_oracle.py).
+    144x160 pads 23040 keys to 32768; 256x256 and 512x512 are the BASELINE cfg4 / cfg5 image sizes."""
+    from oracle import nunet_oracle as O
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(n, 1, h, w, generator=g) * 2
+    t = (torch.rand(n, 1, h, w, generator=g) > 0.7).float()
+    t[0, 0, : h // 2] = 0                                   # a large label-free region
+    xd = x.to(DEV).requires_grad_(True)
+    loss = nunet_amd.losses.LovaszHingeLoss()(xd, t.to(DEV))
+    loss.backward()
+    xo = x.double().requires_grad_(True)
+    ref = O.lovasz_hinge(xo.squeeze(1), t.double().squeeze(1))
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref)) < 2e-5 * max(1.0, float(ref))
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xo.grad.numpy(), atol=3e-7, rtol=2e-3)
     with pytest.raises(L.NunetError):
-        crit(torch.zeros(1, 1, 256, 256, device=DEV), torch.zeros(1, 1, 256, 256, device=DEV))   # > 16384 px: refused loudly
+        big = torch.zeros(1, 1, 2048, 4096, device=DEV)                                         # 2^23 px: refused loudly
+        nunet_amd.losses.LovaszHingeLoss()(big, big)
 
 
 def test_device_input_pipeline_matches_host_pipeline(synth):
@@ -546,3 +568,17 @@ def test_device_input_pipeline_matches_host_pipeline(synth):
     e = np.rot90((m8[1] / 255.0).transpose(2, 0, 1), k=1, axes=(1, 2))
     np.testing.assert_array_equal(mk[1], e.astype(np.float32))
     assert D.draw_augmentation(8).dtype == torch.int32
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 8, 12), (1, 4, 5, 7), (3, 2, 96, 96)])
+def test_sigmoid_masks_u8(shape):
+    """Mask export of the evaluation driver (reference val.py:100-105): (sigmoid(x) * 255).astype('uint8')."""
+    from nunet_amd.metrics import sigmoid_masks_u8
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(*shape, generator=g) * 4
+    x.view(-1)[:4] = torch.tensor([-100.0, 100.0, 0.0, 20.0])
+    got = sigmoid_masks_u8(x.to(DEV)).cpu()
+    ref = torch.from_numpy((torch.sigmoid(x).numpy() * 255).astype("uint8"))
+    d = (got.int() - ref.int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-3     # expf vs torch's exp: off-by-one at a truncation edge only
+    assert got.view(-1)[0] == 0 and got.view(-1)[1] == 255 and got.view(-1)[2] == 127

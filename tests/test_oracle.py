@@ -98,3 +98,19 @@ def test_numpy_restatements_match_torch():
     np.testing.assert_array_equal(O.maxpool2x2_np(x), torch.nn.functional.max_pool2d(xt, 2, 2).numpy())
     up = torch.nn.functional.interpolate(xt, scale_factor=2, mode="bilinear", align_corners=True).numpy()
     np.testing.assert_allclose(O.upsample2x_bilinear_ac_np(x), up, atol=5e-6)
+
+
+def test_oracle_lovasz_hinge_matches_reference_goldens():
+    """The Lovasz-hinge restatement (oracle, used as the checker for image sizes the fixtures do not hold) against
+    the reference's own outputs (tests/golden/lovasz.npz, written by make_golden.py from losses.py)."""
+    import torch
+    from conftest import load_golden
+    from oracle import nunet_oracle as O
+    g = load_golden("lovasz")
+    for tag in ("a", "b", "c"):
+        x = torch.from_numpy(g["x_" + tag]).double().requires_grad_(True)
+        t = torch.from_numpy(g["t_" + tag]).double()
+        loss = O.lovasz_hinge(x.squeeze(1) if x.dim() == 4 else x, t.squeeze(1) if t.dim() == 4 else t)
+        loss.backward()
+        assert abs(float(loss) - float(g["loss_" + tag])) < 2e-6 * max(1.0, float(g["loss_" + tag])), tag
+        np.testing.assert_allclose(x.grad.numpy(), g["dx_" + tag], atol=1e-7, rtol=1e-4, err_msg=tag)

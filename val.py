@@ -12,7 +12,7 @@ import yaml
 
 import nunet_amd
 from nunet_amd import archs
-from nunet_amd.metrics import iou_counts, iou_from_counts
+from nunet_amd.metrics import iou_counts, iou_from_counts, sigmoid_masks_u8
 from nunet_amd.utils import AverageMeter
 
 
@@ -48,10 +48,10 @@ def main():
             meter.update(iou_from_counts(iou_counts(out.contiguous(), tb)), xb.size(0))
             if not args.no_images:
                 from PIL import Image
-                prob = torch.sigmoid(out).cpu().numpy()
-                for i in range(prob.shape[0]):
+                masks = sigmoid_masks_u8(out).cpu().numpy()              # uint8 on the device: 4x fewer D2H bytes
+                for i in range(masks.shape[0]):
                     for c in range(config['num_classes']):
-                        Image.fromarray((prob[i, c] * 255).astype('uint8')).save(
+                        Image.fromarray(masks[i, c]).save(
                             os.path.join('outputs', config['name'], str(c), 'val_%04d.jpg' % (k + i)))
     print('IoU: %.4f' % meter.avg)
 
