@@ -119,14 +119,14 @@ template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
 // The global loads of the NEXT (item, channel chunk) are issued into registers before the
 // current chunk's MFMA sweep, so HBM latency hides under compute and under the previous
 // tile's epilogue, and co-resident workgroups de-synchronise their load/compute/store phases.
-template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR = false>
+template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR = false, bool DB = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
   typedef Mma<T> M;
   constexpr int PS = C::PS, EPV = C::EPV, BN = C::BN, BM = C::BM, NT = C::NT, KS = C::KS, OS = C::OS;
 
   // one LDS arena: [halo | weights] during the K loop, [BM][OS] output staging in the epilogue
-  __shared__ __attribute__((aligned(16))) T s_buf[C::STAGE_ELEMS];
+  __shared__ __attribute__((aligned(16))) T s_buf[(DB ? 2 : 1) * C::STAGE_ELEMS];   // DB: two [halo | weights] stages
   __shared__ int s_hidx[BM];         // tile-invariant: halo index of output row m
   __shared__ int s_mxy[BM];          // tile-invariant: packed (ni, ly, lx) of row m, -1 unused
   __shared__ int s_hxy[C::HPMAX];    // tile-invariant: packed (ni, hy, hx) of halo pixel, -1 unused
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       } else wreg[k] = zero16<T>();
     }
   };
-  auto write_lds = [&]() {
+  auto write_lds = [&](T* const s_halo, T* const s_w) {
 #if defined(NUNET_ABL) && (NUNET_ABL & 2)
     if (abl_written) return;
     abl_written = true;
@@ -267,52 +267,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   // K-split kernels walk channel CHUNKS [c_lo, c_hi) of their slice; plain kernels walk channels
   auto chunk_kb = [&](int c) { return c < p.nch0 ? c * C::KC : p.C0 + (c - p.nch0) * C::KC; };
   auto chunk_kc = [&](int c) { return min(C::KC, (c < p.nch0 ? p.C0 : p.Cin) - chunk_kb(c)); };
-  int item = blockIdx.x;
-  if (item >= p.nItems) return;
-  Item cur = decode(item);
-  set_hgp(cur);
-  int cc = 0, c_hi = 0;
-  int kb = 0, kc = 0;
-  if constexpr (SK) { cc = cur.ks * p.nch / p.S; c_hi = (cur.ks + 1) * p.nch / p.S; kb = chunk_kb(cc); kc = chunk_kc(cc); }
-  else { kc = min(C::KC, (kb < p.C0 ? p.C0 : p.Cin) - kb); }
-  load_regs(cur, kb, kc);
-  bool first_chunk = true;
   constexpr int NSTEP = 9 * KS;
-
-  while (true) {
-    __syncthreads();  // previous chunk's fragment reads / previous item's epilogue reads are done
-    write_lds();
-    if (first_chunk) {
-      for (int m = tid; m < BM; m += NT) {
-        const int code = s_mxy[m];
-        int gp = -1;
-        if (code >= 0) {
-          const int n = cur.n0 + (code >> 20), y = cur.y0 + ((code >> 10) & 1023), x = cur.x0 + (code & 1023);
-          gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
-        }
-        s_gpix[m] = gp;
-      }
-    }
-    __syncthreads();
-    // prefetch the next (item, chunk) into registers
-    int nkb = kb + kc, nkc = 0, nitem = item, ncc = cc + 1, nc_hi = c_hi;
-    Item nxt = cur;
-    bool have_next = true;
-    bool last_chunk;
-    if constexpr (SK) last_chunk = ncc >= c_hi; else last_chunk = nkb >= p.Cin;
-    if (last_chunk) {
-      nkb = 0;
-      nitem = item + gridDim.x;
-      if (nitem < p.nItems) {
-        nxt = decode(nitem); set_hgp(nxt);
-        if constexpr (SK) { ncc = nxt.ks * p.nch / p.S; nc_hi = (nxt.ks + 1) * p.nch / p.S; }
-      } else have_next = false;
-    }
-    if (have_next) {
-      if constexpr (SK) { nkb = chunk_kb(ncc); nkc = chunk_kc(ncc); }
-      else nkc = min(C::KC, (nkb < p.C0 ? p.C0 : p.Cin) - nkb);
-      load_regs(nxt, nkb, nkc);
-    }
+  auto sweep = [&](const T* const s_halo, const T* const s_w) {
     // fully unrolled tap x k-step sweep; fragments of step s+1 are read while step s multiplies
 #if defined(NUNET_ABL) && (NUNET_ABL & 4)
     if (p.N < 0)
@@ -339,8 +295,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
           for (int b = 0; b < SN; ++b) M::mma(acc[a][b], fa[cu][a], fb[cu][b]);
       }
     }
-    first_chunk = false;
-    if (SK && last_chunk) {
+  };
+  auto epi_sk = [&](const Item& cur, const int item) {
       // ---- K-split epilogue: this slice's fp32 partial tile goes to its slab (plain stores,
       // 128-byte runs per half-wave); splitk_finalize_kernel sums the slabs deterministically
       float* slab = p.slabs + (size_t)cur.ks * p.slab_stride;
@@ -441,9 +397,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
           }
         }
       }
-      if (!have_next) break;
-      cur = nxt; item = nitem; first_chunk = true;
-    } else if (last_chunk) {
+  };
+  auto epi_plain = [&](const Item& cur, T* const s_out) {
       // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
       // BNR: the y1 vectors of this thread's store units are requested NOW, so their latency hides under
       // the accumulator -> LDS transposition below instead of being exposed once per unit in the store loop
@@ -463,7 +418,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
         }
       }
       __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
-      T* const s_out = s_buf;
 #pragma unroll
       for (int b = 0; b < SN; ++b) {
         const int cl = (wn * SN + b) * 32 + r;  // channel within the tile
@@ -587,6 +541,60 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
           atomicAdd(&st[p.Cout + cur.co0 + c], s2);
         }
       }
+  };
+  int item = blockIdx.x;
+  if (item >= p.nItems) return;
+  Item cur = decode(item);
+  set_hgp(cur);
+  int cc = 0, c_hi = 0;
+  int kb = 0, kc = 0;
+  if constexpr (SK) { cc = cur.ks * p.nch / p.S; c_hi = (cur.ks + 1) * p.nch / p.S; kb = chunk_kb(cc); kc = chunk_kc(cc); }
+  else { kc = min(C::KC, (kb < p.C0 ? p.C0 : p.Cin) - kb); }
+  load_regs(cur, kb, kc);
+  bool first_chunk = true;
+
+  while (true) {
+    __syncthreads();  // previous chunk's fragment reads / previous item's epilogue reads are done
+    write_lds(s_halo, s_w);
+    if (first_chunk) {
+      for (int m = tid; m < BM; m += NT) {
+        const int code = s_mxy[m];
+        int gp = -1;
+        if (code >= 0) {
+          const int n = cur.n0 + (code >> 20), y = cur.y0 + ((code >> 10) & 1023), x = cur.x0 + (code & 1023);
+          gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
+        }
+        s_gpix[m] = gp;
+      }
+    }
+    __syncthreads();
+    // prefetch the next (item, chunk) into registers
+    int nkb = kb + kc, nkc = 0, nitem = item, ncc = cc + 1, nc_hi = c_hi;
+    Item nxt = cur;
+    bool have_next = true;
+    bool last_chunk;
+    if constexpr (SK) last_chunk = ncc >= c_hi; else last_chunk = nkb >= p.Cin;
+    if (last_chunk) {
+      nkb = 0;
+      nitem = item + gridDim.x;
+      if (nitem < p.nItems) {
+        nxt = decode(nitem); set_hgp(nxt);
+        if constexpr (SK) { ncc = nxt.ks * p.nch / p.S; nc_hi = (nxt.ks + 1) * p.nch / p.S; }
+      } else have_next = false;
+    }
+    if (have_next) {
+      if constexpr (SK) { nkb = chunk_kb(ncc); nkc = chunk_kc(ncc); }
+      else nkc = min(C::KC, (nkb < p.C0 ? p.C0 : p.Cin) - nkb);
+      load_regs(nxt, nkb, nkc);
+    }
+    sweep(s_halo, s_w);
+    first_chunk = false;
+    if (SK && last_chunk) {
+      epi_sk(cur, item);
+      if (!have_next) break;
+      cur = nxt; item = nitem; first_chunk = true;
+    } else if (last_chunk) {
+      epi_plain(cur, s_buf);
       if (!have_next) break;
       cur = nxt; item = nitem; first_chunk = true;
     }
