@@ -96,9 +96,9 @@ struct ConvP {
   float* bn_sums;                         // [2][Cout]: sum dz, sum dz * xhat (atomically accumulated)
 };
 
-template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
-  static constexpr int WM = WM_, WN = WN_, SM = SM_, SN = SN_;
-  static constexpr int NT = 64 * WM * WN;
+template <typename T, int WM_, int WN_, int SM_, int SN_, int KG_ = 1> struct ConvCfg {
+  static constexpr int WM = WM_, WN = WN_, SM = SM_, SN = SN_, KG = KG_;
+  static constexpr int NT = 64 * WM * WN * KG;     // KG wave groups share the tile and split the MFMA steps of every chunk
   static constexpr int BM = 32 * SM * WM;
   static constexpr int BN = 32 * SN * WN;
   static constexpr int EPV = Tr<T>::EPV;
@@ -119,9 +119,9 @@ template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
 // The global loads of the NEXT (item, channel chunk) are issued into registers before the
 // current chunk's MFMA sweep, so HBM latency hides under compute and under the previous
 // tile's epilogue, and co-resident workgroups de-synchronise their load/compute/store phases.
-template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR = false, bool DB = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
-  typedef ConvCfg<T, WM, WN, SM, SN> C;
+template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR = false, bool DB = false, int KG = 1>
+__global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
+  typedef ConvCfg<T, WM, WN, SM, SN, KG> C;
   typedef Mma<T> M;
   constexpr int PS = C::PS, EPV = C::EPV, BN = C::BN, BM = C::BM, NT = C::NT, KS = C::KS, OS = C::OS;
 
@@ -136,7 +136,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   T* const s_halo = s_buf;
   T* const s_w = s_buf + C::HALO_ELEMS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+  // KG > 1: wave group kg owns the MFMA steps st with st % KG == kg of every chunk (twice the waves per SIMD to hide
+  // LDS and MFMA latency when the grid offers one workgroup per CU); group 0 collects the partial sums at the end
+  const int kg = KG > 1 ? wave_all / (WM * WN) : 0;
+  const int wave = KG > 1 ? wave_all % (WM * WN) : wave_all;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
   const int HW2 = p.TW + 2, HH2 = p.TH + 2;
@@ -268,22 +272,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
   auto chunk_kb = [&](int c) { return c < p.nch0 ? c * C::KC : p.C0 + (c - p.nch0) * C::KC; };
   auto chunk_kc = [&](int c) { return min(C::KC, (c < p.nch0 ? p.C0 : p.Cin) - chunk_kb(c)); };
   constexpr int NSTEP = 9 * KS;
-  auto sweep = [&](const T* const s_halo, const T* const s_w) {
-    // fully unrolled tap x k-step sweep; fragments of step s+1 are read while step s multiplies
+  // steps of wave group G: st = G, G + KG, ...; fragments of the group's next step are read while the current one multiplies
+  auto sweep_g = [&](const T* const s_halo, const T* const s_w, auto gtag) {
+    constexpr int G = decltype(gtag)::value;
+    constexpr int NS = (NSTEP - G + KG - 1) / KG;       // steps of this group
 #if defined(NUNET_ABL) && (NUNET_ABL & 4)
     if (p.N < 0)
 #endif
     {
       typename M::Frag fa[2][SM], fb[2][SN];
+      {
+        constexpr int st0 = G, tap0 = st0 / KS, ks0 = st0 % KS;
 #pragma unroll
-      for (int a = 0; a < SM; ++a) fa[0][a] = M::load(&s_halo[abase[a] + toff[0]]);
+        for (int a = 0; a < SM; ++a) fa[0][a] = M::load(&s_halo[abase[a] + toff[tap0] + ks0 * 16]);
 #pragma unroll
-      for (int b = 0; b < SN; ++b) fb[0][b] = M::load(&s_w[bbase + b * 32 * PS]);
+        for (int b = 0; b < SN; ++b) fb[0][b] = M::load(&s_w[bbase + (tap0 * BN + b * 32) * PS + ks0 * 16]);
+      }
 #pragma unroll
-      for (int st = 0; st < NSTEP; ++st) {
-        const int cu = st & 1;
-        if (st + 1 < NSTEP) {
-          const int tap = (st + 1) / KS, ks = (st + 1) % KS;
+      for (int j = 0; j < NS; ++j) {
+        const int cu = j & 1;
+        if (j + 1 < NS) {
+          const int st = (j + 1) * KG + G;
+          const int tap = st / KS, ks = st % KS;
 #pragma unroll
           for (int a = 0; a < SM; ++a) fa[cu ^ 1][a] = M::load(&s_halo[abase[a] + toff[tap] + ks * 16]);
 #pragma unroll
@@ -296,10 +306,43 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
       }
     }
   };
+  auto sweep = [&](const T* const s_halo, const T* const s_w) {
+    if constexpr (KG == 1) sweep_g(s_halo, s_w, std::integral_constant<int, 0>{});
+    else {
+      if (kg == 0) sweep_g(s_halo, s_w, std::integral_constant<int, 0>{});
+      else sweep_g(s_halo, s_w, std::integral_constant<int, 1>{});
+    }
+  };
+  // KG > 1, end of an item: group 1 hands its partial accumulators to group 0 through LDS (placed behind the
+  // epilogue's output staging so that the two never overlap), then every register->memory step below is group 0's
+  auto collect_groups = [&]() {
+    if constexpr (KG > 1) {
+      __syncthreads();   // every wave is done with the halo / weights of the last chunk
+      float* const s_kg = reinterpret_cast<float*>(s_buf + BM * OS) ;   // [WM*WN waves][SM*SN*16][64 lanes]
+      if (kg == 1) {
+#pragma unroll
+        for (int a = 0; a < SM; ++a)
+#pragma unroll
+          for (int b = 0; b < SN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s_kg[((wave * SM * SN + a * SN + b) * 16 + i) * 64 + lane] = acc[a][b][i]; acc[a][b][i] = 0.f; }
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int a = 0; a < SM; ++a)
+#pragma unroll
+          for (int b = 0; b < SN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] += s_kg[((wave * SM * SN + a * SN + b) * 16 + i) * 64 + lane];
+      }
+    }
+  };
   auto epi_sk = [&](const Item& cur, const int item) {
       // ---- K-split epilogue: this slice's fp32 partial tile goes to its slab (plain stores,
       // 128-byte runs per half-wave); splitk_finalize_kernel sums the slabs deterministically
       float* slab = p.slabs + (size_t)cur.ks * p.slab_stride;
+      if (kg == 0) {
 #pragma unroll
       for (int b = 0; b < SN; ++b) {
         const int co = cur.co0 + (wn * SN + b) * 32 + r;
@@ -312,6 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
             acc[a][b][i] = 0.f;
           }
         }
+      }
       }
       if constexpr (SK) {
         if (p.sk_cnt) {
@@ -418,6 +462,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
         }
       }
       __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
+      if (kg == 0) {
 #pragma unroll
       for (int b = 0; b < SN; ++b) {
         const int cl = (wn * SN + b) * 32 + r;  // channel within the tile
@@ -442,6 +487,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
           s2 += __shfl_xor(s2, 32);
           if (h == 0) { s_red[(wm * BN + cl) * 2 + 0] = s1; s_red[(wm * BN + cl) * 2 + 1] = s2; }
         }
+      }
       }
       __syncthreads();
       constexpr int SEGS = BN / EPV;
@@ -590,10 +636,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(ConvP p) {
     sweep(s_halo, s_w);
     first_chunk = false;
     if (SK && last_chunk) {
+      collect_groups();
       epi_sk(cur, item);
       if (!have_next) break;
       cur = nxt; item = nitem; first_chunk = true;
     } else if (last_chunk) {
+      collect_groups();
       epi_plain(cur, s_buf);
       if (!have_next) break;
       cur = nxt; item = nitem; first_chunk = true;
@@ -764,11 +812,21 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
     }
   }
   p.nItems = (int)items;
+  // KG = 2 (8 waves share the tile, each group takes every other MFMA step of a chunk): when the grid offers at most
+  // one workgroup per CU anyway, twice the waves per SIMD hide LDS/MFMA latency. 16-bit types only (LDS budget of the
+  // cross-group hand-over). NUNET_CONV_KG: 0 off, 1 auto (items <= NUNET_CONV_KG_MAXITEMS), 2 always.
+  static int kg_mode = -1, kg_max_items = 0;
+  if (kg_mode < 0) {
+    const char* e = getenv("NUNET_CONV_KG"); kg_mode = e ? atoi(e) : 0;
+    e = getenv("NUNET_CONV_KG_MAXITEMS"); kg_max_items = e ? atoi(e) : 300;
+  }
+  const bool use_kg = sizeof(T) == 2 && !bnr && !p.sk_cnt && (kg_mode == 2 || (kg_mode == 1 && items <= kg_max_items));
   // persistent grid: resident workgroups only, item counts balanced across them
   const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN + (d->bn_y ? 8192 : 0);
   long per_cu = (long)(160 * 1024 / lds_bytes);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2048 / C::NT) per_cu = 2048 / C::NT;
+  if (use_kg) per_cu = 1;   // 8 waves x > 128 registers: one workgroup per CU
   const long resident = 256 * per_cu;
   const long rounds = (items + resident - 1) / resident;
   const long grid = (items + rounds - 1) / rounds;
@@ -777,7 +835,10 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   ProfScope ps(C::BN == 32 ? PC_CONV_M256N32 : PC_CONV_M128N64,  /* BN 64 configs share a class */ 2.0 * 9 * acin * p.Cout * px,
                (px * (acin + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
   if (p.S > 1) {
-    hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+    if constexpr (sizeof(T) == 2) {
+      if (use_kg) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true, false, false, 2>), dim3((unsigned)grid), dim3(2 * C::NT), 0, st, p);
+    }
+    if (!use_kg) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
     if (p.sk_cnt) return nunet_check_launch("conv3x3 (K-split, in-kernel finalize)");
     SplitFinP f;
     f.slabs = p.slabs; f.slab_stride = p.slab_stride; f.S = p.S; f.bias = p.bias;
@@ -790,6 +851,12 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
     if (bnr) hipLaunchKernelGGL((splitk_finalize_kernel<T, true>), dim3((unsigned)fg), dim3(256), 0, st, f);
     else hipLaunchKernelGGL((splitk_finalize_kernel<T, false>), dim3((unsigned)fg), dim3(256), 0, st, f);
     return nunet_check_launch("conv3x3 (K-split)");
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (use_kg) {
+      hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, false, false, 2>), dim3((unsigned)grid), dim3(2 * C::NT), 0, st, p);
+      return nunet_check_launch("conv3x3 (2 wave groups)");
+    }
   }
   if (bnr) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   else hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
