@@ -105,3 +105,21 @@ def test_cfg3_deep_supervision_bs16_loss_is_mean_of_heads(synth):
         assert rel(a.detach().cpu(), b) < 1e-4
     ref_loss = sum(float(O.bce_dice_loss(b, t.float())) for b in ref) / 4
     assert abs(float(loss.detach()) - ref_loss) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(3, 48, 80), (2, 16, 16), (5, 32, 64), (2, 112, 16), (7, 96, 96), (16, 192, 192)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_shape_sweep_logits_and_loss_match_oracle(shape, dtype, tol, synth):
+    """Non-square and odd-batch geometries: every pyramid level picks its own tiling (regular, multi-image, stacked
+    rows, K-split), so a sweep over shapes exercises the combinations the fixed goldens do not. Train-mode logits and
+    BCE-Dice loss against the fp32 CPU oracle."""
+    n, h, w = shape
+    cfg = (n, h, w, 3, 1, False, True, True)
+    m, st, x, t = build(cfg, synth, dtype=dtype)
+    m.train()
+    out, loss, iou = run_step(m, x, t, False)
+    ref = oracle_logits(st, x, 1, False, True)
+    assert rel(out.detach().cpu(), ref) < tol, (shape, dtype)
+    ref_loss = float(O.bce_dice_loss(ref, t.float()))
+    assert abs(float(loss.detach()) - ref_loss) < (2e-5 if dtype == "fp32" else 2e-2)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
