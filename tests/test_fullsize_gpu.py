@@ -114,6 +114,8 @@ def test_shape_sweep_logits_and_loss_match_oracle(shape, dtype, tol, synth):
     rows, K-split), so a sweep over shapes exercises the combinations the fixed goldens do not. Train-mode logits and
     BCE-Dice loss against the fp32 CPU oracle."""
     n, h, w = shape
+    if dtype != "fp32" and n * (h // 16) * (w // 16) < 16:
+        pytest.skip("BatchNorm over < 16 values per channel at level 4: ill-conditioned, 16-bit rounding decides signs")
     cfg = (n, h, w, 3, 1, False, True, True)
     m, st, x, t = build(cfg, synth, dtype=dtype)
     m.train()
