@@ -257,7 +257,9 @@ int32_t nunet_plan_num_heads(const nunet_plan* p);
 /* params: flat fp32, reference parameters() order (OIHW conv weights).
  * bnbuf:  flat fp32 [running_mean, running_var] per BN in state_dict order.
  * nbt:    int64 per BN layer.
- * input:  NCHW fp32. logits: [heads][N][K][H][W] fp32. */
+ * input:  NCHW fp32. logits: [heads][N][K][H][W] fp32.
+ * training: bit 0 = training mode (batch statistics, running-stat update); bit 1 = the packed weights in `arena`
+ * are current (left so by nunet_plan_update / nunet_plan_repack on these parameters): skip the repack. */
 int nunet_plan_forward(nunet_plan* p, const float* params, float* bnbuf, int64_t* nbt,
                        const float* input, void* arena, float* logits, int32_t training,
                        nunet_stream_t s);
@@ -274,6 +276,15 @@ int nunet_plan_backward_phase(nunet_plan* p, const float* params, const float* d
                               float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s);
 int nunet_plan_grad_scratch(const nunet_plan* p, int64_t* byte_offset, int64_t* bucket0_floats,
                             int64_t* total_floats);
+/* Fused optimiser step on the plan's buffers, replacing unpack (nunet_plan_backward_phase bit 2) + nunet_sgd_step +
+ * the repack of the next forward: gradient scratch (optionally exchanged between ranks) -> torch.optim.SGD step
+ * (reference trains.py:229-231; lr from device memory, momentum buffer `momentum`, weight decay, nesterov,
+ * grad_scale = 1/world) on the fp32 master parameters -> both packed weight layouts. `grads` (flat OIHW, may be NULL)
+ * receives the scaled gradients. */
+int nunet_plan_update(nunet_plan* p, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
+                      int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s);
+/* Repack the weight layouts from the fp32 parameters (what nunet_plan_forward does first unless told they are current). */
+int nunet_plan_repack(nunet_plan* p, const float* params, void* arena, nunet_stream_t s);
 /* Multi-lane issue (default on; env NUNET_MULTISTREAM=0 disables): the plan forks onto
  * its own streams (one per pyramid level + one per level for weight gradients), with event
  * dependencies per buffer, and re-joins `s` before returning control - all work is ordered

@@ -115,6 +115,121 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused optimiser step: native-layout gradient scratch -> SGD(momentum, weight decay, nesterov) on the fp32 master
+// parameters -> both packed 16-bit weight layouts of the NEXT forward/backward, one launch (replaces
+// unpack_kernel + sgd_kernel + pack_kernel, which ran one after the other with nothing to overlap them).
+// Same block -> (layer, 32 Cout x 32 Cin tile) map as pack_kernel; the tile's gradients arrive [tap][co][ci]
+// (coalesced along ci) and meet the OIHW parameters / momentum through LDS. The block of input-channel tile 0
+// also steps the layer's conv bias and BatchNorm gamma / beta; blocks past the last tile own the 1x1 heads
+// (sum of their gradient slabs, then the same step). torch.optim.SGD semantics (reference trains.py:229-231).
+// ---------------------------------------------------------------------------------------------------------
+struct UpdP { float* params; float* mom; const float* scratch; float* grads; const float* lr; float momc, wd, gscale; int nesterov; int nconv; };
+
+__device__ __forceinline__ float sgd_one(float p, float g, float* m, const UpdP& u, float lr) {
+  float gv = g + u.wd * p;
+  if (u.momc != 0.f) {
+    const float b = u.momc * (*m) + gv;
+    *m = b;
+    gv = u.nesterov ? gv + u.momc * b : b;
+  }
+  return p - lr * gv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void update_kernel(UpdP u, T* __restrict__ arena, PackTab tab, UnpackTab ut) {
+  __shared__ float s_t[32][32 * 9 + 1];
+  __shared__ float s_g[32][32 * 9 + 1];
+  const float lr = u.lr[0];
+  if ((int)blockIdx.x >= tab.ntiles) {
+    // ---- 1x1 head: sum the gradient slabs (fixed order), then the step; <= 264 elements
+    const UnpackEnt en = ut.e[u.nconv + (int)blockIdx.x - tab.ntiles];
+    const float* dw = u.scratch + en.src;
+    const int tot = en.cout * en.cin * en.taps + en.nvec * en.cout;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+      float g = 0.f;
+      for (int sl = 0; sl < en.nslab; ++sl) g += dw[(long long)sl * tot + e];
+      g *= u.gscale;
+      const long long idx = en.dst + e;
+      if (u.grads) u.grads[idx] = g;
+      float m = u.mom[idx];
+      const float pn = sgd_one(u.params[idx], g, &m, u, lr);
+      u.mom[idx] = m; u.params[idx] = pn;
+    }
+    return;
+  }
+  int e = 0;
+  while (e + 1 < tab.n && (int)blockIdx.x >= tab.tile0[e + 1]) ++e;
+  const PackEnt en = tab.e[e];
+  const UnpackEnt ue = ut.e[e];
+  const int t = blockIdx.x - tab.tile0[e];
+  const int nci = (en.cinpad + 31) / 32;
+  const int co0 = (t / nci) * 32, ci0 = (t % nci) * 32;
+  const float* w = u.params + en.src;
+  const float* dw = u.scratch + ue.src;
+  const int cw = min(32, en.cin - ci0);            // real input channels in this tile (<= 0: pure padding)
+  const int rw = min(32, en.cout - co0);
+#pragma unroll 6
+  for (int i = threadIdx.x; i < 32 * 288; i += blockDim.x) {
+    const int ro = i / 288, k = i - ro * 288;      // k = ci_local*9 + tap
+    float v = 0.f;
+    if (ro < rw && k < cw * 9) v = w[((long long)(co0 + ro) * en.cin + ci0) * 9 + k];
+    s_t[ro][k] = v;
+  }
+#pragma unroll 6
+  for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) {   // scratch dw[tap][co][cinpad], ci fastest
+    const int ci = i & 31, ro = (i >> 5) & 31, tap = i >> 10;
+    float v = 0.f;
+    if (ro < rw && ci < cw) v = dw[((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + ci];
+    s_g[ro][ci * 9 + tap] = v;
+  }
+  __syncthreads();
+#pragma unroll 6
+  for (int i = threadIdx.x; i < 32 * 288; i += blockDim.x) {
+    const int ro = i / 288, k = i - ro * 288;
+    if (ro < rw && k < cw * 9) {
+      const long long idx = en.src + ((long long)(co0 + ro) * en.cin + ci0) * 9 + k;
+      const float g = s_g[ro][k] * u.gscale;
+      if (u.grads) u.grads[idx] = g;
+      float m = u.mom[idx];
+      const float pn = sgd_one(s_t[ro][k], g, &m, u, lr);
+      u.mom[idx] = m; u.params[idx] = pn;
+      s_t[ro][k] = pn;
+    }
+  }
+  if (ci0 == 0) {
+    // conv bias, BN gamma, BN beta of the output channels of this tile (they follow the weights in both arenas)
+    const long long nw = (long long)en.cout * en.cin * 9;
+    for (int i = threadIdx.x; i < ue.nvec * rw; i += blockDim.x) {
+      const int v = i / rw, c = co0 + (i - v * rw);
+      const long long idx = ue.dst + nw + (long long)v * en.cout + c;
+      const float g = dw[9LL * en.cout * en.cinpad + (long long)v * en.cout + c] * u.gscale;
+      if (u.grads) u.grads[idx] = g;
+      float m = u.mom[idx];
+      const float pn = sgd_one(u.params[idx], g, &m, u, lr);
+      u.mom[idx] = m; u.params[idx] = pn;
+    }
+  }
+  __syncthreads();
+  T* wf = arena + en.wf;
+#pragma unroll 6
+  for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) {   // wf[tap][co][ci], ci fastest
+    const int ci = i & 31, ro = (i >> 5) & 31, tap = i >> 10;
+    if (ro < rw && ci0 + ci < en.cinpad)
+      wf[((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + ci] = from_f32<T>(s_t[ro][ci * 9 + tap]);
+  }
+  if (en.wd >= 0) {
+    T* wd = arena + en.wd;
+#pragma unroll 6
+    for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) { // wd[8-tap][ci][co], co fastest
+      const int ro = i & 31, ci = (i >> 5) & 31, tap = i >> 10;
+      if (ro < rw && ci < cw)
+        wd[((long long)(8 - tap) * en.cin + ci0 + ci) * en.cout + co0 + ro] = from_f32<T>(s_t[ro][ci * 9 + tap]);
+    }
+  }
+}
+
 template <typename T> static int launch_pack(const float* params, void* arena_t, PackTab& tab, long long maxn, hipStream_t st) {
   (void)maxn;
   int nt = 0;
@@ -771,7 +886,8 @@ static int blk_index(const nunet_plan* P, int i, int in_prefix_zero_only) {
   return -1;
 }
 
-extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnbuf, int64_t* nbt, const float* input, void* arena, float* logits, int32_t training, nunet_stream_t s) {
+extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnbuf, int64_t* nbt, const float* input, void* arena, float* logits, int32_t training_flags, nunet_stream_t s) {
+  const int32_t training = training_flags & 1;
   NUNET_REQUIRE(P && params && input && arena && logits, "plan_forward: null pointer");
   NUNET_REQUIRE(bnbuf, "plan_forward: bnbuf (running stats) required");
   hipStream_t st = (hipStream_t)s;
@@ -796,7 +912,8 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   // forward (NUNET_GS_FWD=1) is neutral. Both stay off by default.
   static int pack_lanes = -1, gs_fwd = -1;
   if (pack_lanes < 0) { const char* e = getenv("NUNET_PACK_LANES"); pack_lanes = e ? atoi(e) : 0; e = getenv("NUNET_GS_FWD"); gs_fwd = e ? atoi(e) : 0; }
-  if (!pack_lanes) {
+  const bool skip_pack = (training_flags & 2) != 0;   // the caller vouches that nunet_plan_update / _repack left the packed weights current
+  if (!pack_lanes && !skip_pack) {
     S.name("pack");
     hipStream_t ls = S.begin(0, {}, {R_WP + 0, R_WP + 1, R_WP + 2, R_WP + 3, R_WP + 4});
     if (dt == NUNET_F32) rc = launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, ls);
@@ -804,7 +921,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
     else rc = launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
     S.end();
   }
-  for (int l = 0; l < 5 && rc == NUNET_OK && pack_lanes; ++l) {
+  for (int l = 0; l < 5 && rc == NUNET_OK && pack_lanes && !skip_pack; ++l) {
     if (P->ptab_lvl[l].n == 0) continue;
     // 1: each level on its own lane; 2: level 0 on the chain lane (needed first), the rest one after the other on lane 3
     S.name("pack%d", l);
@@ -914,6 +1031,42 @@ extern "C" int nunet_plan_grad_scratch(const nunet_plan* P, int64_t* byte_offset
   *bucket0_floats = P->gs_bucket0;
   *total_floats = (int64_t)(P->gs_floats - P->stats_floats * NUNET_BN_SUM_REPLICAS);
   return NUNET_OK;
+}
+
+// Fused optimiser step on the plan's own buffers (update_kernel above): scratch -> SGD -> repacked weights.
+// `grads` (flat OIHW arena) is optional: when given it receives the (scaled) gradients as nunet_plan_backward would
+// have left them. Afterwards the packed weights in `arena` are current: the next nunet_plan_forward may be called
+// with bit 1 of `training` set (skip the repack).
+extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
+                                 int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s) {
+  NUNET_REQUIRE(P && params && momentum && arena && lr_dev, "plan_update: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  PackTab& tab = P->ptab;
+  int nt = 0;
+  for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
+  tab.tile0[tab.n] = nt; tab.ntiles = nt;
+  UpdP u;
+  u.params = params; u.mom = momentum; u.scratch = (const float*)AB(arena, P->off_gs); u.grads = grads; u.lr = lr_dev;
+  u.momc = mom; u.wd = wd; u.gscale = grad_scale; u.nesterov = nesterov; u.nconv = tab.n;
+  const int nheads = P->utab.n - tab.n;
+  ProfScope ps(PC_SGD, 0, (double)P->nparams * (grads ? 28.0 : 24.0), st);
+  void* wp = AB(arena, P->off_wpack);
+  const dim3 grid(nt + nheads), blk(512);
+  if (P->cfg.dtype == NUNET_F32) hipLaunchKernelGGL((update_kernel<float>), grid, blk, 0, st, u, (float*)wp, tab, P->utab);
+  else if (P->cfg.dtype == NUNET_BF16) hipLaunchKernelGGL((update_kernel<bf16_t>), grid, blk, 0, st, u, (bf16_t*)wp, tab, P->utab);
+  else hipLaunchKernelGGL((update_kernel<f16_t>), grid, blk, 0, st, u, (f16_t*)wp, tab, P->utab);
+  return nunet_check_launch("plan_update");
+}
+
+// Repack the 16-bit weight layouts from the fp32 master parameters (what nunet_plan_forward does first unless told
+// that they are current): needed once before a loop that relies on nunet_plan_update, and after the parameters were
+// changed by anything else (checkpoint load, a stock optimiser).
+extern "C" int nunet_plan_repack(nunet_plan* P, const float* params, void* arena, nunet_stream_t s) {
+  NUNET_REQUIRE(P && params && arena, "plan_repack: null pointer");
+  char* wpack = AB(arena, P->off_wpack);
+  if (P->cfg.dtype == NUNET_F32) return launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, (hipStream_t)s);
+  if (P->cfg.dtype == NUNET_BF16) return launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, (hipStream_t)s);
+  return launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, (hipStream_t)s);
 }
 
 // phases: 1 = clear scratch, heads and the last anti-diagonal's blocks (75 % of the gradient bytes);

@@ -349,3 +349,29 @@ def test_training_log_follows_reference(synth):
     dv = np.abs(rows[:, 2] - ref[:, 4])
     assert dv[0] < 0.05 and dv[-1] < 0.30 and np.median(dv) < 0.15, (rows[:, 2], ref[:, 4])
     assert np.all(np.isfinite(rows)) and rows[:, 2].max() < 2.0
+
+
+@pytest.mark.parametrize("dtype", ["fp32"])     # (16-bit storage: two runs of this ill-conditioned net diverge by 20 % in three steps)
+def test_fused_update_equals_unpack_sgd_pack(dtype, synth):
+    """nunet_plan_update (scratch -> SGD -> repacked weights in one launch) against the three separate launches it
+    replaces (unpack into the OIHW gradient arena, nunet_sgd_step, repack at the next forward): same parameters,
+    momentum and gradients after three steps with momentum, weight decay and nesterov."""
+    from nunet_amd.trainer import TrainStep
+    cfg = GOLDEN_CASES["a_n2_32x32_k1"]
+    res = []
+    for fused in (False, True):
+        m, st, x, t = build(cfg, synth, dtype=dtype)
+        m.train()
+        ts = TrainStep(m, tuple(x.shape), lr=5e-2, momentum=0.9, weight_decay=1e-3, nesterov=True, use_graph=False,
+                       fused_update=fused, keep_grads=True)
+        xd, td = x.to(DEV), t.to(DEV)
+        for _ in range(3):
+            ts.step(xd, td)
+        torch.cuda.synchronize()
+        res.append((ts.eng.flat_params.clone(), ts.mom.clone(), ts.eng.flat_grads.clone()))
+    (p0, m0, g0), (p1, m1, g1) = res
+    # identical arithmetic per element; the gradient scratch itself carries atomic-order noise between two runs
+    tol = 5e-4 if dtype == "fp32" else 5e-3     # lr 5e-2 x three steps x the gradient noise
+    assert float((p0 - p1).abs().max()) < tol * float(p0.abs().max())
+    assert float((m0 - m1).norm() / m0.norm()) < (5e-3 if dtype == "fp32" else 0.15)
+    assert float((g0 - g1).norm() / g0.norm()) < (5e-3 if dtype == "fp32" else 0.15)
