@@ -283,6 +283,10 @@ int nunet_plan_grad_scratch(const nunet_plan* p, int64_t* byte_offset, int64_t* 
  * receives the scaled gradients. */
 int nunet_plan_update(nunet_plan* p, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
                       int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s);
+/* The same optimiser step without the repack (the next nunet_plan_forward repacks as usual): gradient scratch -> SGD,
+ * one launch instead of unpack + nunet_sgd_step, no OIHW gradient round trip unless `grads` is given. */
+int nunet_plan_sgd(nunet_plan* p, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
+                   int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s);
 /* Repack the weight layouts from the fp32 parameters (what nunet_plan_forward does first unless told they are current). */
 int nunet_plan_repack(nunet_plan* p, const float* params, void* arena, nunet_stream_t s);
 /* Multi-lane issue (default on; env NUNET_MULTISTREAM=0 disables): the plan forks onto

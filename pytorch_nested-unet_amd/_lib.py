@@ -115,6 +115,7 @@ _SIG = {
     "nunet_plan_grad_scratch": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "nunet_plan_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
     "nunet_plan_repack": (_i32, [_vp, _vp, _vp, _vp]),
+    "nunet_plan_sgd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
     "nunet_plan_feature": (_i64, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "nunet_plan_set_multistream": (_i32, [_vp, _i32]),
     "nunet_plan_set_lanes": (_i32, [_vp, C.POINTER(_vp), _i32]),

@@ -230,6 +230,48 @@ __global__ __launch_bounds__(512) void update_kernel(UpdP u, T* __restrict__ are
   }
 }
 
+// unpack_kernel with the optimiser step as its epilogue: the gradient is gathered from the native-layout scratch and
+// consumed on the spot (no OIHW gradient round trip, one launch less); `u.grads` optionally still receives it.
+__global__ __launch_bounds__(256) void unpack_sgd_kernel(UpdP u, UnpackTab tab) {
+  const UnpackEnt en = tab.e[blockIdx.y];
+  const float* dw = u.scratch + en.src;
+  const float lr = u.lr[0];
+  const long long nw = (long long)en.cout * en.cin * en.taps;
+  const long long total = nw + (long long)en.nvec * en.cout;
+  if (en.nslab > 1) {
+    if (blockIdx.x != 0) return;
+    for (int e = threadIdx.x; e < (int)total; e += blockDim.x) {   // 1x1 head: slabs summed in fixed order
+      float g = 0.f;
+      for (int sl = 0; sl < en.nslab; ++sl) g += dw[(long long)sl * total + e];
+      g *= u.gscale;
+      const long long idx = en.dst + e;
+      if (u.grads) u.grads[idx] = g;
+      float m = u.mom[idx];
+      const float pn = sgd_one(u.params[idx], g, &m, u, lr);
+      u.mom[idx] = m; u.params[idx] = pn;
+    }
+    return;
+  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float g;
+    if (i < nw) {
+      const int tap = (int)(i % en.taps);
+      const long long t = i / en.taps;
+      const int ci = (int)(t % en.cin);
+      const int co = (int)(t / en.cin);
+      g = dw[((long long)tap * en.cout + co) * en.cinpad + ci];
+    } else {
+      g = dw[(long long)en.taps * en.cout * en.cinpad + (i - nw)];
+    }
+    g *= u.gscale;
+    const long long idx = en.dst + i;
+    if (u.grads) u.grads[idx] = g;
+    float m = u.mom[idx];
+    const float pn = sgd_one(u.params[idx], g, &m, u, lr);
+    u.mom[idx] = m; u.params[idx] = pn;
+  }
+}
+
 template <typename T> static int launch_pack(const float* params, void* arena_t, PackTab& tab, long long maxn, hipStream_t st) {
   (void)maxn;
   int nt = 0;
@@ -1056,6 +1098,22 @@ extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, 
   else if (P->cfg.dtype == NUNET_BF16) hipLaunchKernelGGL((update_kernel<bf16_t>), grid, blk, 0, st, u, (bf16_t*)wp, tab, P->utab);
   else hipLaunchKernelGGL((update_kernel<f16_t>), grid, blk, 0, st, u, (f16_t*)wp, tab, P->utab);
   return nunet_check_launch("plan_update");
+}
+
+// Optimiser step straight from the gradient scratch (unpack_sgd_kernel): replaces nunet_plan_backward_phase bit 2 +
+// nunet_sgd_step; the weights are repacked by the next nunet_plan_forward as usual.
+extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
+                              int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s) {
+  NUNET_REQUIRE(P && params && momentum && arena && lr_dev, "plan_sgd: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  UpdP u;
+  u.params = params; u.mom = momentum; u.scratch = (const float*)AB(arena, P->off_gs); u.grads = grads; u.lr = lr_dev;
+  u.momc = mom; u.wd = wd; u.gscale = grad_scale; u.nesterov = nesterov; u.nconv = P->ptab.n;
+  int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
+  if (gx > 512) gx = 512;
+  ProfScope ps(PC_SGD, 0, (double)P->nparams * (grads ? 24.0 : 20.0), st);
+  hipLaunchKernelGGL(unpack_sgd_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, u, P->utab);
+  return nunet_check_launch("plan_sgd");
 }
 
 // Repack the 16-bit weight layouts from the fp32 master parameters (what nunet_plan_forward does first unless told

@@ -21,7 +21,7 @@ from .parallel import allreduce_flat_
 
 class TrainStep:
     def __init__(self, model, batch_shape, lr=1e-3, momentum=0.9, weight_decay=1e-4, nesterov=False,
-                 use_graph=True, process_group=None, keep_grads=False, fused_update=None):
+                 use_graph=True, process_group=None, keep_grads=True, fused_update=None):
         self.model = model
         self.eng = model.engine()
         dev = self.eng.device
@@ -50,7 +50,7 @@ class TrainStep:
         # fused optimiser step (nunet_plan_update: scratch -> SGD -> repacked weights, one launch); the flat OIHW
         # gradients (p.grad views) are only materialised with keep_grads=True. Measured round 1: the tiled kernel takes
         # 152 us against 101 us for unpack + sgd + pack as three streaming launches, so it is opt-in for now.
-        self.fused_update = (os.environ.get("NUNET_FUSED_UPDATE", "0") != "0") if fused_update is None else bool(fused_update)
+        self.fused_update = int(os.environ.get("NUNET_FUSED_UPDATE", "0")) if fused_update is None else int(fused_update)   # 0 three streaming launches (default, fastest), 1 one tile kernel incl. repack, 2 unpack+sgd fused
         self.keep_grads = keep_grads
         self._packed = False          # the arena's packed weights match the fp32 parameters
         self.g_fb = None
@@ -65,7 +65,7 @@ class TrainStep:
         lib, eng, pl = L.lib(), self.eng, self.pl
         st = L.stream()
         L.check(lib.nunet_plan_forward(pl.handle, L.ptr(eng.flat_params), L.ptr(eng.bnbuf), L.ptr(eng.nbt),
-                                       L.ptr(self.x), L.ptr(pl.arena), L.ptr(self.logits), 3 if (self.fused_update and self._packed) else 1, st), "plan_forward")
+                                       L.ptr(self.x), L.ptr(pl.arena), L.ptr(self.logits), 3 if (self.fused_update == 1 and self._packed) else 1, st), "plan_forward")
         L.check(lib.nunet_loss_step(L.ptr(self.logits), L.ptr(self.t), self.n, self.per, self.heads, L.ptr(self.loss_ws),
                                     L.ptr(self.dlogits), L.ptr(self.loss_out), L.ptr(self.meters), st), "loss_step")
         pl.trained_forward = True
@@ -82,6 +82,11 @@ class TrainStep:
     def _update(self):
         """scratch -> SGD -> repacked weights in one launch (replaces unpack + sgd + the next forward's repack)."""
         eng, pl = self.eng, self.pl
+        if self.fused_update == 2:      # gradient scratch -> SGD in one launch; the next forward repacks
+            L.check(L.lib().nunet_plan_sgd(pl.handle, L.ptr(eng.flat_params), L.ptr(self.mom), L.ptr(pl.arena), L.ptr(self.lr),
+                                           self.momentum, self.wd, 1 if self.nesterov else 0, 1.0 / self.world,
+                                           L.ptr(eng.flat_grads) if self.keep_grads else None, L.stream()), "plan_sgd")
+            return
         L.check(L.lib().nunet_plan_update(pl.handle, L.ptr(eng.flat_params), L.ptr(self.mom), L.ptr(pl.arena), L.ptr(self.lr),
                                           self.momentum, self.wd, 1 if self.nesterov else 0, 1.0 / self.world,
                                           L.ptr(eng.flat_grads) if self.keep_grads else None, L.stream()), "plan_update")
@@ -89,7 +94,7 @@ class TrainStep:
     def sync_weights(self):
         """Repack the plan's 16-bit weights from the fp32 parameters: call after changing the parameters by anything
         other than step() (load_state_dict, a stock optimiser) when fused_update is on."""
-        if self.fused_update:
+        if self.fused_update == 1:
             L.check(L.lib().nunet_plan_repack(self.pl.handle, L.ptr(self.eng.flat_params), L.ptr(self.pl.arena), L.stream()), "plan_repack")
             self._packed = True
 
@@ -201,7 +206,7 @@ class TrainStep:
             else:
                 self.g_fb.replay()
         else:
-            if self.fused_update and not self._packed:
+            if self.fused_update == 1 and not self._packed:
                 self.sync_weights()
             self._eager_step()
         self.steps += 1
