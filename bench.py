@@ -170,8 +170,8 @@ def main():
                    "conv3x3_wgrad(Cout>=64)": "wgrad_pair_kernel", "conv3x3_wgrad(Cout=32)": "wgrad_pair_kernel"}.get(top["name"])
             if pat and args.dtype == "bf16" and hw == 96 and n == 16:
                 for kname, rec in pmc.items():
-                    # (the BM128 class is the plain instantiation: neither K-split nor fused BN reduce)
-                    if pat in kname and "DF16b" in kname or (pat == "void conv3x3_kernel<" and kname.startswith(pat) and "false, false>" in kname):
+                    # (the BM128 class is the plain instantiation: template args ..., SK = false, BNR = false, ...)
+                    if pat in kname and "DF16b" in kname or (pat == "void conv3x3_kernel<" and kname.startswith(pat) and ", E, false, false," in kname):
                         roofline["traffic"] = rec["hbm_bytes_per_launch_corrected"]
                         roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                         roofline["algorithmic_bytes_per_launch"] = top["bytes"] / top["launches"]
