@@ -19,6 +19,15 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _library_built():
+    """The tests bind libnunet.so through ctypes; a fresh checkout has only sources (the .so is git-ignored), so it is
+    compiled here when absent (hipcc cross-compiles gfx950 without a GPU; __graft_entry__.build() does the same)."""
+    L = importlib.import_module("pytorch_nested-unet_amd._lib")
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return importlib.import_module("pytorch_nested-unet_amd")
