@@ -63,10 +63,12 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 // image of N * SH rows, virtual row v = n * SH + y + 1, rows with v % SH == 0 are zero separators that
 // serve as bottom halo of image n - 1 and top halo of image n. Tiles are TH virtual rows x full width,
 // so small images (12 x 12 at level 3 of a 96 x 96 input) fill a 128-pixel tile to 86 % instead of 56 %.
-__device__ __forceinline__ int map_pixel(int n, int y, int x, int N, int H, int W, int SH) {
+// SHinv = ceil(2^32 / SH): y / SH == umulhi(y, SHinv) exactly while y * SH < 2^32 (y < N * SH <= 2^20, SH <= 2^12 by the
+// chooser's bound) - the compiler's generic 32-bit division is ~30 VALU instructions, paid per staging unit and tile.
+__device__ __forceinline__ int map_pixel(int n, int y, int x, int N, int H, int W, int SH, unsigned SHinv) {
   if (SH) {
     if (y < 0 || x < 0 || x >= W) return -1;
-    const int n2 = y / SH, yy = y - n2 * SH - 1;
+    const int n2 = (int)__umulhi((unsigned)y, SHinv), yy = y - n2 * SH - 1;
     if (n2 >= N || yy < 0) return -1;
     return (n2 * H + yy) * W + x;
   }
@@ -89,6 +91,7 @@ struct ConvP {
   int N, H, W, Cin, Cout;
   int NI, TH, TW, tilesX, tilesY, tilesG, nCoT, nItems;
   int SH;                // stacked-rows tiling: H + 1 (0 = off), see map_pixel
+  unsigned SHinv;        // ceil(2^32 / SH)
   int S, nch0, nch;      // K-split: slices, channel chunks of source 0 / total (SK kernels only)
   float* slabs;          // [S][pixels][Cout] fp32 partial sums
   unsigned* sk_cnt;      // per (tile, Cout-tile) arrival counters (zero before and after every launch); NULL: separate finalize kernel
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
       int gp = -1;
       if (hcode[k] >= 0) {
         const int n = it.n0 + (hcode[k] >> 20), y = it.y0 + ((hcode[k] >> 10) & 1023) - 1, x = it.x0 + (hcode[k] & 1023) - 1;
-        gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
+        gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
       }
       hgp[k] = gp;
     }
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
         int gp = -1;
         if (code >= 0) {
           const int n = cur.n0 + (code >> 20), y = cur.y0 + ((code >> 10) & 1023), x = cur.x0 + (code & 1023);
-          gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
+          gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
         }
         s_gpix[m] = gp;
       }
@@ -801,7 +804,7 @@ TileGeom nunet_choose_tile(int N, int H, int W, int BM, int HPMAX) {
   // taken only when they beat the best regular tiling by a clear margin (they waste the separator rows)
   static int stacked = -1;
   if (stacked < 0) { const char* e = getenv("NUNET_STACKED_TILES"); stacked = e ? atoi(e) : 1; }
-  if (stacked && W <= BM && (long)N * (H + 1) < (1 << 20)) {
+  if (stacked && W <= BM && (long)N * (H + 1) < (1 << 20) && H + 1 <= 4096) {
     const double best_util = (double)N * H * W / ((double)best.tilesX * best.tilesY * best.tilesG * BM);
     const int VH = N * (H + 1);
     double su = 0.0; int sth = 0;
@@ -830,6 +833,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.bn_y = d->bn_y; p.bn_py = d->bn_py; p.bn_mi = d->bn_mean_invstd; p.bn_gamma = d->bn_gamma; p.bn_beta = d->bn_beta; p.bn_sums = d->bn_sums;
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
+  p.SHinv = g.SH ? (unsigned)(((1ull << 32) + g.SH - 1) / g.SH) : 0u;
   p.nCoT = p.Cout / C::BN;
   long items = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
   // K-split for the grid-starved deep levels: slices of the channel-chunk loop become extra items, each
@@ -971,7 +975,7 @@ struct WgP {
   int N, H, W, Cin;
   int NI, TH, TW, tilesX, tilesY, tilesG;
   int nCoT, nCiT, ksplit, nMT;
-  int SH;
+  int SH; unsigned SHinv;
 };
 
 template <typename T> struct WgCfg {
@@ -1063,23 +1067,24 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
     const int x0 = (b2 % p.tilesX) * p.TW; b2 /= p.tilesX;
     const int y0 = (b2 % p.tilesY) * p.TH;
     const int n0 = (b2 / p.tilesY) * p.NI;
+    // branch-free: a unit outside the image (or past the tile / channel range) reads a page of zeros, so the seven
+    // loads of a tile are independent instructions of one basic block instead of seven guarded blocks
+    const T* const zp = reinterpret_cast<const T*>(g_zero_page);
 #pragma unroll
     for (int k = 0; k < C::NUD; ++k) {
-      dreg[k] = zero16<T>();
-      if (dcode[k] >= 0) {
-        const int n = n0 + (dcode[k] >> 20), y = y0 + ((dcode[k] >> 10) & 1023), x = x0 + (dcode[k] & 1023);
-        const int gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
-        if (gp >= 0) dreg[k] = ld16(dsrc + (size_t)gp * p.PY);
-      }
+      const int cde = dcode[k] >= 0 ? dcode[k] : 0;
+      const int n = n0 + (cde >> 20), y = y0 + ((cde >> 10) & 1023), x = x0 + (cde & 1023);
+      int gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
+      if (dcode[k] < 0) gp = -1;
+      dreg[k] = ld16(gp >= 0 ? dsrc + (size_t)gp * p.PY : zp);
     }
 #pragma unroll
     for (int k = 0; k < C::NUA; ++k) {
-      areg[k] = zero16<T>();
-      if (acode[k] >= 0 && cvalid) {
-        const int n = n0 + (acode[k] >> 20), y = y0 + ((acode[k] >> 10) & 1023) - 1, x = x0 + (acode[k] & 1023) - 1;
-        const int gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH);
-        if (gp >= 0) areg[k] = ld16(asrc + (size_t)gp * apitch + ach);
-      }
+      const int cde = acode[k] >= 0 ? acode[k] : 0;
+      const int n = n0 + (cde >> 20), y = y0 + ((cde >> 10) & 1023) - 1, x = x0 + (cde & 1023) - 1;
+      int gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
+      if (acode[k] < 0 || !cvalid) gp = -1;
+      areg[k] = ld16(gp >= 0 ? asrc + (size_t)gp * apitch + ach : zp);
     }
   };
   auto write_tile = [&](int buf) {
@@ -1189,6 +1194,7 @@ template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p,
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1;
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
+  p.SHinv = g.SH ? (unsigned)(((1ull << 32) + g.SH - 1) / g.SH) : 0u;
   p.nCoT = ceil_div(p.Cout, 32);
   p.nCiT = ceil_div(p.Cin, 32);
   p.nMT = g.tilesX * g.tilesY * g.tilesG;
