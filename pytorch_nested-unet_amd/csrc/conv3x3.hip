@@ -76,6 +76,23 @@ __device__ __forceinline__ int map_pixel(int n, int y, int x, int N, int H, int 
   return -1;
 }
 
+// Branch-free, tiling mode known at compile time (wgrad maps seven staging units per 128-pixel tile: guarded early
+// returns cost it a basic block and an exec-mask round trip per unit).
+template <bool ST>
+__device__ __forceinline__ int map_pixel_t(int n, int y, int x, int N, int H, int W, int SH, unsigned SHinv) {
+  if constexpr (ST) {
+    const int yc = y < 0 ? 0 : y;
+    const int n2 = (int)__umulhi((unsigned)yc, SHinv), yy = yc - n2 * SH - 1;
+    const bool ok = (y >= 0) & (x >= 0) & (x < W) & (n2 < N) & (yy >= 0);
+    const int gp = (n2 * H + yy) * W + x;
+    return ok ? gp : -1;
+  } else {
+    const bool ok = (n < N) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+    const int gp = (n * H + y) * W + x;
+    return ok ? gp : -1;
+  }
+}
+
 // zeros that a staging load of a halo pixel outside the image reads instead of branching (FK kernels): one page covers
 // any channel offset of a 16-byte unit (Cin <= 4096 elements of 2 bytes / 2048 of 4)
 __device__ __attribute__((aligned(64))) uint32_t g_zero_page[2048 + 16];
@@ -1005,7 +1022,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 // waves of a workgroup split the TAPS (3 each) and all walk every pixel of the tile: no cross-wave
 // reduction, 48 accumulator registers per lane. Tiles are double-buffered in LDS; the next tile's
 // global loads are in flight (registers) while the current one multiplies.
-template <typename T>
+template <typename T, bool ST>
 __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
   typedef WgCfg<T> C;
   constexpr int NT = C::NT, BM = C::BM, EPV = C::EPV, SR = C::SR, UPP = C::UPP;
@@ -1074,7 +1091,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
     for (int k = 0; k < C::NUD; ++k) {
       const int cde = dcode[k] >= 0 ? dcode[k] : 0;
       const int n = n0 + (cde >> 20), y = y0 + ((cde >> 10) & 1023), x = x0 + (cde & 1023);
-      int gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
+      int gp = map_pixel_t<ST>(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
       if (dcode[k] < 0) gp = -1;
       dreg[k] = ld16(gp >= 0 ? dsrc + (size_t)gp * p.PY : zp);
     }
@@ -1082,7 +1099,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
     for (int k = 0; k < C::NUA; ++k) {
       const int cde = acode[k] >= 0 ? acode[k] : 0;
       const int n = n0 + (cde >> 20), y = y0 + ((cde >> 10) & 1023) - 1, x = x0 + (cde & 1023) - 1;
-      int gp = map_pixel(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
+      int gp = map_pixel_t<ST>(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
       if (acode[k] < 0 || !cvalid) gp = -1;
       areg[k] = ld16(gp >= 0 ? asrc + (size_t)gp * apitch + ach : zp);
     }
@@ -1175,16 +1192,16 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) { wgrad_body<T>(p, blockIdx.x); }
+template <typename T, bool ST>
+__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) { wgrad_body<T, ST>(p, blockIdx.x); }
 
 // Two independent weight-gradient problems in ONE launch (the two convolutions of a VGGBlock finish
 // their dY at the same point of the backward pass): one kernel boundary less per block and twice
 // the workgroups to fill the chip.
-template <typename T>
+template <typename T, bool ST>
 __global__ __launch_bounds__(192) void wgrad_pair_kernel(WgP pa, WgP pb, int na) {
-  if ((int)blockIdx.x < na) wgrad_body<T>(pa, blockIdx.x);
-  else wgrad_body<T>(pb, blockIdx.x - na);
+  if ((int)blockIdx.x < na) wgrad_body<T, ST>(pa, blockIdx.x);
+  else wgrad_body<T, ST>(pb, blockIdx.x - na);
 }
 
 template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p, int target_override = 0) {
@@ -1220,7 +1237,8 @@ template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStre
   const long grid = wgrad_setup<T>(d, p);
   double fl, by; wgrad_prof<T>(d, p, fl, by);
   ProfScope ps(p.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fl, by, st);
-  hipLaunchKernelGGL((wgrad_kernel<T>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  if (p.SH) hipLaunchKernelGGL((wgrad_kernel<T, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  else hipLaunchKernelGGL((wgrad_kernel<T, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   return nunet_check_launch("wgrad3x3");
 }
 
@@ -1237,7 +1255,12 @@ template <typename T> static int launch_wgrad_pair(const WgPairArgs* w, hipStrea
   double fa, ba, fb, bb; wgrad_prof<T>(w->a, pa, fa, ba);
   { const int keep = g_prof_alg_cin; g_prof_alg_cin = 0; wgrad_prof<T>(w->b, pb, fb, bb); g_prof_alg_cin = keep; }
   ProfScope ps(pa.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fa + fb, ba + bb, st);
-  hipLaunchKernelGGL((wgrad_pair_kernel<T>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
+  if ((pa.SH != 0) != (pb.SH != 0)) {   // different tiling modes (different extents): two launches
+    int rc = launch_wgrad<T>(w->a, st);
+    return rc ? rc : launch_wgrad<T>(w->b, st);
+  }
+  if (pa.SH) hipLaunchKernelGGL((wgrad_pair_kernel<T, true>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
+  else hipLaunchKernelGGL((wgrad_pair_kernel<T, false>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
   return nunet_check_launch("wgrad3x3 (pair)");
 }
 
