@@ -737,6 +737,12 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
   }
   __syncthreads();
   const long long total = p.npix * G;
+  // when the block size is a multiple of G every element a thread visits has the same channel group: the statistics are
+  // summed in registers and meet in LDS once per thread (per-element LDS atomics on G*EPV addresses were most of this kernel)
+  const bool fixed_cg = (blockDim.x % G) == 0;
+  float q1[EPV], q2[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) { q1[e] = 0.f; q2[e] = 0.f; }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cg = (int)(i % G);
     const long long pix = i / G;
@@ -766,8 +772,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
       v.set(e, y);
       if (p.stats) {
         const float d = to_f32(from_f32<T>(y)) - b;   // the stored (rounded) value; not v.get(e) right after v.set(e)
-        atomicAdd(&s_st[co + e], d);
-        atomicAdd(&s_st[p.Cout + co + e], d * d);
+        if (fixed_cg) { q1[e] += d; q2[e] += d * d; }
+        else { atomicAdd(&s_st[co + e], d); atomicAdd(&s_st[p.Cout + co + e], d * d); }
       }
     }
     st16(q, v);
@@ -789,6 +795,11 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
       atomicAdd(&p.bn_sums[(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout + c], s_bn[4 * p.Cout + c]);
   }
   if (p.stats) {
+    if (fixed_cg) {
+      const int co = (threadIdx.x % G) * EPV;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { atomicAdd(&s_st[co + e], q1[e]); atomicAdd(&s_st[p.Cout + co + e], q2[e]); }
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x)
       atomicAdd(&p.stats[(size_t)(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout + c], s_st[c]);
@@ -1108,9 +1119,9 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
     T* sd = s_stage + buf * C::STAGE;
     T* sa = sd + BM * SR;
 #pragma unroll
-    for (int k = 0; k < C::NUD; ++k) if (dcode[k] != -2) st16(&sd[((tid + k * NT) / UPP) * SR + seg * EPV], dreg[k]);
+    for (int k = 0; k < C::NUD; ++k) if ((k + 1) * NT <= BM * UPP || dcode[k] != -2) st16(&sd[((tid + k * NT) / UPP) * SR + seg * EPV], dreg[k]);
 #pragma unroll
-    for (int k = 0; k < C::NUA; ++k) if (acode[k] != -2) st16(&sa[((tid + k * NT) / UPP) * SR + seg * EPV], areg[k]);
+    for (int k = 0; k < C::NUA; ++k) if ((k + 1) * NT <= C::HPMAX * UPP || acode[k] != -2) st16(&sa[((tid + k * NT) / UPP) * SR + seg * EPV], areg[k]);
   };
 
   f32x16 acc[3];
