@@ -76,6 +76,11 @@ __device__ __forceinline__ int map_pixel(int n, int y, int x, int N, int H, int 
   return -1;
 }
 
+// n / d for a divisor fixed per launch: inv = ceil(2^32 / d) (0 for d == 1); exact while n * d < 2^32 (tile and item
+// counts are < 2^20 here). The compiler's generic 32-bit division is ~30 instructions, also for uniform operands.
+__host__ __device__ __forceinline__ unsigned fastdiv_inv(int d) { return d > 1 ? (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d) : 0u; }
+__device__ __forceinline__ int fastdiv(int n, unsigned inv) { return inv ? (int)__umulhi((unsigned)n, inv) : n; }
+
 // Branch-free, tiling mode known at compile time (wgrad maps seven staging units per 128-pixel tile: guarded early
 // returns cost it a basic block and an exec-mask round trip per unit).
 template <bool ST>
@@ -109,6 +114,7 @@ struct ConvP {
   int NI, TH, TW, tilesX, tilesY, tilesG, nCoT, nItems;
   int SH;                // stacked-rows tiling: H + 1 (0 = off), see map_pixel
   unsigned SHinv;        // ceil(2^32 / SH)
+  unsigned invS, invCoT, invTX, invTY;   // fastdiv_inv of S, nCoT, tilesX, tilesY (item decode)
   int S, nch0, nch;      // K-split: slices, channel chunks of source 0 / total (SK kernels only)
   float* slabs;          // [S][pixels][Cout] fp32 partial sums
   unsigned* sk_cnt;      // per (tile, Cout-tile) arrival counters (zero before and after every launch); NULL: separate finalize kernel
@@ -216,11 +222,14 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
   auto decode = [&](int item) {
     Item it;
     it.ks = 0;
-    if constexpr (SK) { it.ks = item % p.S; item /= p.S; }
-    it.co0 = (item % p.nCoT) * BN; item /= p.nCoT;
-    it.x0 = (item % p.tilesX) * p.TW; item /= p.tilesX;
-    it.y0 = (item % p.tilesY) * p.TH;
-    it.n0 = (item / p.tilesY) * p.NI;
+    if constexpr (SK) { const int q = fastdiv(item, p.invS); it.ks = item - q * p.S; item = q; }
+    int q = fastdiv(item, p.invCoT);
+    it.co0 = (item - q * p.nCoT) * BN; item = q;
+    q = fastdiv(item, p.invTX);
+    it.x0 = (item - q * p.tilesX) * p.TW; item = q;
+    q = fastdiv(item, p.invTY);
+    it.y0 = (item - q * p.tilesY) * p.TH;
+    it.n0 = q * p.NI;
     return it;
   };
 
@@ -886,6 +895,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
     }
   }
   p.nItems = (int)items;
+  p.invS = fastdiv_inv(p.S); p.invCoT = fastdiv_inv(p.nCoT); p.invTX = fastdiv_inv(p.tilesX); p.invTY = fastdiv_inv(p.tilesY);
   // KG = 2 (8 waves share the tile, each group takes every other MFMA step of a chunk): when the grid offers at most
   // one workgroup per CU anyway, twice the waves per SIMD hide LDS/MFMA latency. 16-bit types only (LDS budget of the
   // cross-group hand-over). NUNET_CONV_KG: 0 off, 1 auto (items <= NUNET_CONV_KG_MAXITEMS), 2 always.
@@ -1004,6 +1014,7 @@ struct WgP {
   int NI, TH, TW, tilesX, tilesY, tilesG;
   int nCoT, nCiT, ksplit, nMT;
   int SH; unsigned SHinv;
+  unsigned invTX, invTY;   // fastdiv_inv(tilesX), fastdiv_inv(tilesY)
 };
 
 template <typename T> struct WgCfg {
@@ -1091,10 +1102,10 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
 
   Vec16<T> dreg[C::NUD], areg[C::NUA];
   auto load_tile = [&](int mt) {
-    int b2 = mt;
-    const int x0 = (b2 % p.tilesX) * p.TW; b2 /= p.tilesX;
-    const int y0 = (b2 % p.tilesY) * p.TH;
-    const int n0 = (b2 / p.tilesY) * p.NI;
+    const int q1 = fastdiv(mt, p.invTX), q2 = fastdiv(q1, p.invTY);
+    const int x0 = (mt - q1 * p.tilesX) * p.TW;
+    const int y0 = (q1 - q2 * p.tilesY) * p.TH;
+    const int n0 = q2 * p.NI;
     // branch-free: a unit outside the image (or past the tile / channel range) reads a page of zeros, so the seven
     // loads of a tile are independent instructions of one basic block instead of seven guarded blocks
     const T* const zp = reinterpret_cast<const T*>(g_zero_page);
@@ -1223,6 +1234,7 @@ template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p,
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
   p.SHinv = g.SH ? (unsigned)(((1ull << 32) + g.SH - 1) / g.SH) : 0u;
+  p.invTX = fastdiv_inv(g.tilesX); p.invTY = fastdiv_inv(g.tilesY);
   p.nCoT = ceil_div(p.Cout, 32);
   p.nCiT = ceil_div(p.Cin, 32);
   p.nMT = g.tilesX * g.tilesY * g.tilesG;
