@@ -66,14 +66,14 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 // SHinv = ceil(2^32 / SH): y / SH == umulhi(y, SHinv) exactly while y * SH < 2^32 (y < N * SH <= 2^20, SH <= 2^12 by the
 // chooser's bound) - the compiler's generic 32-bit division is ~30 VALU instructions, paid per staging unit and tile.
 __device__ __forceinline__ int map_pixel(int n, int y, int x, int N, int H, int W, int SH, unsigned SHinv) {
-  if (SH) {
-    if (y < 0 || x < 0 || x >= W) return -1;
-    const int n2 = (int)__umulhi((unsigned)y, SHinv), yy = y - n2 * SH - 1;
-    if (n2 >= N || yy < 0) return -1;
-    return (n2 * H + yy) * W + x;
-  }
-  if (n < N && y >= 0 && y < H && x >= 0 && x < W) return (n * H + y) * W + x;
-  return -1;
+  // branch-free for both modes (selects, no early returns): callers map several staging units back to back
+  const bool st = SH != 0;
+  const int yc = y < 0 ? 0 : y;
+  const int n2 = (int)__umulhi((unsigned)yc, SHinv);
+  const int yy = yc - n2 * SH - 1;                 // stacked: row inside image n2, -1 on a separator row
+  const int ni = st ? n2 : n, yi = st ? yy : y;
+  const bool ok = (y >= 0) & (x >= 0) & (x < W) & (ni < N) & (yi >= 0) & (st | (y < H));
+  return ok ? (ni * H + yi) * W + x : -1;
 }
 
 // n / d for a divisor fixed per launch: inv = ceil(2^32 / d) (0 for d == 1); exact while n * d < 2^32 (tile and item
