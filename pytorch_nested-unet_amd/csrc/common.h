@@ -92,6 +92,33 @@ __host__ __device__ __forceinline__ int bn_sum_replicas(int C) {
   return r < 1 ? 1 : (r > NUNET_BN_SUM_REPLICAS ? NUNET_BN_SUM_REPLICAS : r);
 }
 
+// Linear index -> (channel group, x, y, n) of an [N][H][W][G] iteration space. The element-wise kernels used three 64-bit
+// divisions per element (>100 instructions each on this ISA): with the extents fixed per launch they become multiplies
+// by ceil(2^32 / d), exact while index * d < 2^32 (checked on the host; the 64-bit path stays for larger tensors).
+struct Dec4 { int G, W, H; unsigned iG, iW, iH; int fast; };
+static inline unsigned dec_inv(int d) { return d > 1 ? (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d) : 0u; }
+static inline Dec4 make_dec4(long long total, int G, int W, int H) {
+  Dec4 d; d.G = G; d.W = W; d.H = H; d.iG = dec_inv(G); d.iW = dec_inv(W); d.iH = dec_inv(H);
+  const long long mx = G > W ? (G > H ? G : H) : (W > H ? W : H);
+  d.fast = total > 0 && total * mx < (1ll << 32) ? 1 : 0;
+  return d;
+}
+__device__ __forceinline__ int dec_div(int n, unsigned inv) { return inv ? (int)__umulhi((unsigned)n, inv) : n; }
+__device__ __forceinline__ void dec4(const Dec4& d, long long i, int& cg, long long& o, int& x, int& y, int& n) {
+  if (d.fast) {
+    const int ii = (int)i;
+    const int oo = dec_div(ii, d.iG); cg = ii - oo * d.G;
+    const int t = dec_div(oo, d.iW); x = oo - t * d.W;
+    n = dec_div(t, d.iH); y = t - n * d.H;
+    o = oo;
+  } else {
+    cg = (int)(i % d.G); o = i / d.G;
+    x = (int)(o % d.W);
+    const long long t = o / d.W;
+    y = (int)(t % d.H); n = (int)(t / d.H);
+  }
+}
+
 template <typename T> struct Vec16 {
   // zero-initialised: set() of a 16-bit element read-modify-writes its 32-bit word, and doing that on an
   // indeterminate word is undefined (it miscompiled for fp16 on the odd elements of words 0 and 1)

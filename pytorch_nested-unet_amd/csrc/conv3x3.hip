@@ -109,6 +109,7 @@ struct ConvP {
   void* dst0; void* dst1;
   int D0, D1, Q0, Q1;
   int slot_w; unsigned acc0_mask; int acc1;
+  unsigned inv_slot_w;   // fastdiv_inv(slot_w): the destination slot of a channel without a division per store unit
   float* stats;
   int N, H, W, Cin, Cout;
   int NI, TH, TW, tilesX, tilesY, tilesG, nCoT, nItems;
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
                   }
                 }
                 T* q; bool accum;
-                if (co < p.D0) { q = (T*)p.dst0 + (size_t)gp * p.Q0 + co; accum = (p.acc0_mask >> (p.slot_w > 0 ? co / p.slot_w : 0)) & 1u; }
+                if (co < p.D0) { q = (T*)p.dst0 + (size_t)gp * p.Q0 + co; accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u; }
                 else { q = (T*)p.dst1 + (size_t)gp * p.Q1 + (co - p.D0); accum = p.acc1 != 0; }
                 const Vec16<T> o = accum ? ld16(q) : zero16<T>();
                 Vec16<T> v;
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
             T* q; bool accum;
             if (co < p.D0) {
               q = (T*)p.dst0 + (size_t)gp * p.Q0 + co;
-              accum = (p.acc0_mask >> (p.slot_w > 0 ? co / p.slot_w : 0)) & 1u;
+              accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u;
             } else {
               q = (T*)p.dst1 + (size_t)gp * p.Q1 + (co - p.D0);
               accum = p.acc1 != 0;
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
 // -> T, routed to the two destinations with the per-slot accumulate mask, BatchNorm partial sums.
 struct SplitFinP {
   const float* slabs; long long slab_stride; int S; const float* bias;
-  void* dst0; void* dst1; int D0, D1, Q0, Q1; int slot_w; unsigned acc0_mask; int acc1;
+  void* dst0; void* dst1; int D0, D1, Q0, Q1; int slot_w; unsigned acc0_mask; int acc1; unsigned inv_slot_w;
   float* stats; long long npix; int Cout;
   const void* bn_y; int bn_py; const float* bn_mi; const float* bn_gamma; const float* bn_beta; float* bn_sums;   // see ConvP
 };
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
       }
     }
     T* q; bool accum;
-    if (co < p.D0) { q = (T*)p.dst0 + pix * p.Q0 + co; accum = (p.acc0_mask >> (p.slot_w > 0 ? co / p.slot_w : 0)) & 1u; }
+    if (co < p.D0) { q = (T*)p.dst0 + pix * p.Q0 + co; accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u; }
     else { q = (T*)p.dst1 + pix * p.Q1 + (co - p.D0); accum = p.acc1 != 0; }
     const Vec16<T> o = accum ? ld16(q) : zero16<T>();
     Vec16<T> v;
@@ -863,7 +864,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.src0 = d->src0; p.src1 = d->src1; p.C0 = d->C0; p.C1 = d->C1; p.P0 = d->P0; p.P1 = d->P1;
   p.w = d->wpack; p.bias = d->bias;
   p.dst0 = d->dst0; p.dst1 = d->dst1; p.D0 = d->D0; p.D1 = d->D1; p.Q0 = d->Q0; p.Q1 = d->Q1;
-  p.slot_w = d->acc_slot_w; p.acc0_mask = d->acc0_mask; p.acc1 = d->acc1;
+  p.slot_w = d->acc_slot_w; p.acc0_mask = d->acc0_mask; p.acc1 = d->acc1; p.inv_slot_w = fastdiv_inv(d->acc_slot_w);
   p.stats = d->stats;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1; p.Cout = d->D0 + d->D1;
   const bool bnr = d->bn_y != nullptr;
@@ -939,7 +940,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
     SplitFinP f;
     f.slabs = p.slabs; f.slab_stride = p.slab_stride; f.S = p.S; f.bias = p.bias;
     f.dst0 = p.dst0; f.dst1 = p.dst1; f.D0 = p.D0; f.D1 = p.D1; f.Q0 = p.Q0; f.Q1 = p.Q1;
-    f.slot_w = p.slot_w; f.acc0_mask = p.acc0_mask; f.acc1 = p.acc1; f.stats = p.stats;
+    f.slot_w = p.slot_w; f.acc0_mask = p.acc0_mask; f.acc1 = p.acc1; f.inv_slot_w = p.inv_slot_w; f.stats = p.stats;
     f.npix = (long long)d->N * d->H * d->W; f.Cout = p.Cout;
     f.bn_y = p.bn_y; f.bn_py = p.bn_py; f.bn_mi = p.bn_mi; f.bn_gamma = p.bn_gamma; f.bn_beta = p.bn_beta; f.bn_sums = p.bn_sums;
     long long fg = (f.npix * (p.Cout / C::EPV) + 255) / 256;

@@ -50,22 +50,34 @@ int nunet_zero_async(void* p, size_t bytes, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // layout: NCHW fp32 -> NHWC T with zero channel padding
 // ---------------------------------------------------------------------------
+// One thread per (pixel, 16-byte channel group): consecutive threads write consecutive 16 bytes; blockIdx.y is the image,
+// so there is no division in the kernel (the first version spent two 64-bit divisions per 2-byte element).
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, int H, int W, T* __restrict__ y, int cpad) {
-  const int64_t total = (int64_t)N * H * W * cpad;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cpad);
-    const int64_t pix = i / cpad;
-    const int64_t hw = (int64_t)H * W;
-    const int n = (int)(pix / hw);
-    const int64_t rem = pix - n * hw;
-    y[i] = (c < C) ? from_f32<T>(x[((int64_t)n * C + c) * hw + rem]) : from_f32<T>(0.f);
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int hw, T* __restrict__ y, int cpad, int gshift) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int n = blockIdx.y;
+  const int groups = 1 << gshift;
+  const float* xi = x + (size_t)n * C * hw;
+  T* yi = y + (size_t)n * hw * cpad;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < (hw << gshift); j += gridDim.x * blockDim.x) {
+    const int pix = j >> gshift, c0 = (j & (groups - 1)) * EPV;
+    Vec16<T> v;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) v.set(e, c0 + e < C ? xi[(size_t)(c0 + e) * hw + pix] : 0.f);
+    st16(yi + (size_t)pix * cpad + c0, v);
   }
 }
 template <typename T> static int launch_nchw_to_nhwc(const float* x, int N, int C, int H, int W, void* y, int cpad, hipStream_t st) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int groups = cpad / EPV;
+  int gshift = 0;
+  while ((1 << gshift) < groups) ++gshift;
+  NUNET_REQUIRE(cpad % EPV == 0 && (1 << gshift) == groups && N <= 65535, "nchw_to_nhwc: cpad=%d must be a power-of-two number of 16-byte groups", cpad);
+  const long long hw = (long long)H * W;
+  NUNET_REQUIRE(hw * groups < (1ll << 31), "nchw_to_nhwc: image too large");
   const int64_t total = (int64_t)N * H * W * cpad;
   ProfScope ps(PC_LAYOUT, 0, (double)total * sizeof(T) + (double)N * C * H * W * 4, st);
-  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, x, N, C, H, W, (T*)y, cpad);
+  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(hw * groups, 256, 1024), N), dim3(256), 0, st, x, C, (int)hw, (T*)y, cpad, gshift);
   return nunet_check_launch("nchw_to_nhwc");
 }
 extern "C" int nunet_nchw_to_nhwc(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t dtype, void* y, int32_t cpad, nunet_stream_t s) {
@@ -471,16 +483,13 @@ extern "C" int nunet_bn_relu_bwd_apply(const nunet_bn_bwd_desc* d, nunet_stream_
 // MaxPool2d(2,2)
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int PX, T* __restrict__ y, int PY, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int PX, T* __restrict__ y, int PY, int N, int H, int W, int C, Dec4 dc) {
   constexpr int EPV = Tr<T>::EPV;
   const int G = C / EPV, H2 = H / 2, W2 = W / 2;
   const int64_t total = (int64_t)N * H2 * W2 * G;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % G);
-    const int64_t q = i / G;
-    const int qx = (int)(q % W2);
-    const int64_t t = q / W2;
-    const int qy = (int)(t % H2), n = (int)(t / H2);
+    int cg, qx, qy, n; long long q;
+    dec4(dc, i, cg, q, qx, qy, n);
     const int64_t p00 = ((int64_t)n * H + 2 * qy) * W + 2 * qx;
     float mx[EPV];
 #pragma unroll
@@ -496,16 +505,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int PX, const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int PX, const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc) {
   constexpr int EPV = Tr<T>::EPV;
   const int G = C / EPV, H2 = H / 2, W2 = W / 2;
   const int64_t total = (int64_t)N * H2 * W2 * G;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % G);
-    const int64_t q = i / G;
-    const int qx = (int)(q % W2);
-    const int64_t t = q / W2;
-    const int qy = (int)(t % H2), n = (int)(t / H2);
+    int cg, qx, qy, n; long long q;
+    dec4(dc, i, cg, q, qx, qy, n);
     const int64_t p00 = ((int64_t)n * H + 2 * qy) * W + 2 * qx;
     Vec16<T> v[4];
 #pragma unroll
@@ -539,13 +545,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 template <typename T> static int launch_maxpool_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
   ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * 1.25, st);
-  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C);
+  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
   return nunet_check_launch("maxpool_fwd");
 }
 template <typename T> static int launch_maxpool_bwd(int N, int H, int W, int C, const void* x, int PX, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
   ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * (acc ? 3.25 : 2.25), st);
-  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C);
+  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
   return nunet_check_launch("maxpool_bwd");
 }
 static int ew_check(const char* what, int dtype, int N, int H, int W, int C, int p0, int p1) {
@@ -578,18 +584,15 @@ __device__ __forceinline__ void up_taps(int dst, float scale, int n_in, int& i0,
   l1 = src - (float)i0;
 }
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, int PX, T* __restrict__ y, int PY, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, int PX, T* __restrict__ y, int PY, int N, int H, int W, int C, Dec4 dc) {
   constexpr int EPV = Tr<T>::EPV;
   const int G = C / EPV, HO = 2 * H, WO = 2 * W;
   const float sy = HO > 1 ? (float)(H - 1) / (float)(HO - 1) : 0.f;
   const float sx = WO > 1 ? (float)(W - 1) / (float)(WO - 1) : 0.f;
   const int64_t total = (int64_t)N * HO * WO * G;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % G);
-    const int64_t o = i / G;
-    const int ox = (int)(o % WO);
-    const int64_t t = o / WO;
-    const int oy = (int)(t % HO), n = (int)(t / HO);
+    int cg, ox, oy, n; long long o;
+    dec4(dc, i, cg, o, ox, oy, n);
     int y0, y1, x0, x1; float ly, lx;
     up_taps(oy, sy, H, y0, y1, ly);
     up_taps(ox, sx, W, x0, x1, lx);
@@ -606,18 +609,15 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
 }
 // gather form of the transposed interpolation: one thread per low-res pixel
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc) {
   constexpr int EPV = Tr<T>::EPV;
   const int G = C / EPV, HO = 2 * H, WO = 2 * W;
   const float sy = HO > 1 ? (float)(H - 1) / (float)(HO - 1) : 0.f;
   const float sx = WO > 1 ? (float)(W - 1) / (float)(WO - 1) : 0.f;
   const int64_t total = (int64_t)N * H * W * G;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % G);
-    const int64_t o = i / G;
-    const int ix = (int)(o % W);
-    const int64_t t = o / W;
-    const int iy = (int)(t % H), n = (int)(t / H);
+    int cg, ix, iy, n; long long o;
+    dec4(dc, i, cg, o, ix, iy, n);
     int ylo = 0, yhi = HO - 1, xlo = 0, xhi = WO - 1;
     if (sy > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / sy) - 1); yhi = min(HO - 1, (int)ceilf((float)(iy + 1) / sy) + 1); }
     if (sx > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / sx) - 1); xhi = min(WO - 1, (int)ceilf((float)(ix + 1) / sx) + 1); }
@@ -651,13 +651,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 template <typename T> static int launch_up_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * 4 * H * W * (C / Tr<T>::EPV);
   ProfScope ps(PC_UP_FWD, 0, (double)N * H * W * C * sizeof(T) * 5.0, st);
-  hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C);
+  hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, 2 * W, 2 * H));
   return nunet_check_launch("upsample_fwd");
 }
 template <typename T> static int launch_up_bwd(int N, int H, int W, int C, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
   const int64_t total = (int64_t)N * H * W * (C / Tr<T>::EPV);
   ProfScope ps(PC_UP_BWD, 0, (double)N * H * W * C * sizeof(T) * (acc ? 6.0 : 5.0), st);
-  hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C);
+  hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H));
   return nunet_check_launch("upsample_bwd");
 }
 extern "C" int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s) {

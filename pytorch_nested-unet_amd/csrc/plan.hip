@@ -27,7 +27,7 @@ static const int NBF[5] = {32, 64, 128, 256, 512};  // archs1.py:78
 #define HEAD_SLABS 256
 struct PackEnt { long long src, wf, wd; int cout, cin, cinpad, pad_; };
 struct PackTab { int n; int ntiles; PackEnt e[MAXENT]; int tile0[MAXENT + 1]; };
-struct UnpackEnt { long long src, dst; int cout, cin, cinpad, taps, nvec, nslab; };   // nslab > 1: sum of partial slabs (heads)
+struct UnpackEnt { long long src, dst; int cout, cin, cinpad, taps, nvec, nslab; unsigned inv_taps, inv_cin; int fast; };   // inv_*: dec_inv(), fast: 32-bit decode is exact   // nslab > 1: sum of partial slabs (heads)
 struct UnpackTab { int n; int accumulate; UnpackEnt e[MAXENT]; };
 
 // One block per (layer, 32 Cout x 32 Cin tile): the OIHW rows of a tile are contiguous runs of
@@ -103,10 +103,15 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     float v;
     if (i < nw) {
-      const int tap = (int)(i % en.taps);
-      const long long t = i / en.taps;
-      const int ci = (int)(t % en.cin);
-      const int co = (int)(t / en.cin);
+      int tap, ci, co;
+      if (en.fast) {   // (two 64-bit divisions per element were most of this kernel's instructions)
+        const int ii = (int)i, t = dec_div(ii, en.inv_taps);
+        tap = ii - t * en.taps; co = dec_div(t, en.inv_cin); ci = t - co * en.cin;
+      } else {
+        tap = (int)(i % en.taps);
+        const long long t = i / en.taps;
+        ci = (int)(t % en.cin); co = (int)(t / en.cin);
+      }
       v = dw[((long long)tap * en.cout + co) * en.cinpad + ci];
     } else {
       v = dw[(long long)en.taps * en.cout * en.cinpad + (i - nw)];
@@ -255,10 +260,15 @@ __global__ __launch_bounds__(256) void unpack_sgd_kernel(UpdP u, UnpackTab tab) 
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     float g;
     if (i < nw) {
-      const int tap = (int)(i % en.taps);
-      const long long t = i / en.taps;
-      const int ci = (int)(t % en.cin);
-      const int co = (int)(t / en.cin);
+      int tap, ci, co;
+      if (en.fast) {
+        const int ii = (int)i, t = dec_div(ii, en.inv_taps);
+        tap = ii - t * en.taps; co = dec_div(t, en.inv_cin); ci = t - co * en.cin;
+      } else {
+        tap = (int)(i % en.taps);
+        const long long t = i / en.taps;
+        ci = (int)(t % en.cin); co = (int)(t / en.cin);
+      }
       g = dw[((long long)tap * en.cout + co) * en.cinpad + ci];
     } else {
       g = dw[(long long)en.taps * en.cout * en.cinpad + (i - nw)];
@@ -304,6 +314,7 @@ extern "C" int nunet_unpack_wgrad(const float* dw, int32_t cout, int32_t cin, in
   UnpackTab tab; memset(&tab, 0, sizeof(tab));
   tab.n = 1; tab.accumulate = accumulate;
   tab.e[0].src = 0; tab.e[0].dst = 0; tab.e[0].cout = cout; tab.e[0].cin = cin; tab.e[0].cinpad = cin_pad; tab.e[0].taps = 9; tab.e[0].nvec = 0; tab.e[0].nslab = 1;
+  tab.e[0].inv_taps = dec_inv(9); tab.e[0].inv_cin = dec_inv(cin); tab.e[0].fast = 9LL * cout * cin * (cin > 9 ? cin : 9) < (1ll << 32);
   int gx = (int)ceil_div64(9LL * cout * cin, 256 * 4);
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
@@ -529,6 +540,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     if (9LL * c.cout * c.cinpad > P->pack_maxn) P->pack_maxn = 9LL * c.cout * c.cinpad;
     UnpackEnt& ue = P->utab.e[P->utab.n++];
     ue.src = c.gs; ue.dst = c.w_off; ue.cout = c.cout; ue.cin = c.cin; ue.cinpad = c.cinpad; ue.taps = 9; ue.nvec = 3; ue.nslab = 1;
+    ue.inv_taps = dec_inv(9); ue.inv_cin = dec_inv(c.cin); ue.fast = 9LL * c.cout * c.cin * (c.cin > 9 ? c.cin : 9) < (1ll << 32);
     if (9LL * c.cout * c.cin + 3 * c.cout > P->unpack_maxn) P->unpack_maxn = 9LL * c.cout * c.cin + 3 * c.cout;
   };
   for (size_t r = 0; r < P->reg.size(); ++r) { add_conv(P->exec[P->reg[r]].c1); add_conv(P->exec[P->reg[r]].c2); }
@@ -545,7 +557,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   }
   for (size_t k = 0; k < P->heads.size(); ++k) {
     UnpackEnt& ue = P->utab.e[P->utab.n++];
-    ue.src = P->heads[k].gs; ue.dst = P->heads[k].w_off; ue.cout = cfg->num_classes; ue.cin = NBF[0]; ue.cinpad = NBF[0]; ue.taps = 1; ue.nvec = 1; ue.nslab = HEAD_SLABS;
+    ue.src = P->heads[k].gs; ue.dst = P->heads[k].w_off; ue.cout = cfg->num_classes; ue.cin = NBF[0]; ue.cinpad = NBF[0]; ue.taps = 1; ue.nvec = 1; ue.nslab = HEAD_SLABS; ue.inv_taps = 0; ue.inv_cin = dec_inv(NBF[0]); ue.fast = 1;
   }
   PlanRt* rt = new PlanRt();
   rt->lanes_ok = true;
