@@ -176,14 +176,14 @@ class TrainStep:
                 self.tune_result = self.g_fb.tune(iters)
         else:
             self.g_fb = torch.cuda.CUDAGraph()          # forward + loss + backward phase 1
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):   # (the RCCL watchdog thread polls events meanwhile)
                 self._fwd_loss()
                 self._bwd(1)
             self.g_b2 = torch.cuda.CUDAGraph()          # backward phase 2
-            with torch.cuda.graph(self.g_b2):
+            with torch.cuda.graph(self.g_b2, capture_error_mode="thread_local"):   # (the RCCL watchdog thread polls events meanwhile)
                 self._bwd(2)
             self.g_opt = torch.cuda.CUDAGraph()         # unpack + SGD
-            with torch.cuda.graph(self.g_opt):
+            with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):   # (the RCCL watchdog thread polls events meanwhile)
                 if not self.fused_update:
                     self._bwd(4)
                 self._opt()
