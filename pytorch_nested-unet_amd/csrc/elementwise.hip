@@ -194,15 +194,22 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   const int H2 = p.H / 2, W2 = p.W / 2;
   const int64_t nq = (int64_t)p.N * H2 * W2;
   Vec16<T> vq[4];
+  const bool q32 = nq < (1ll << 31);   // 32-bit index decode (a 64-bit division is >100 instructions here)
   auto quad_base = [&](int64_t q) {
+    if (q32) {
+      const unsigned t = (unsigned)q / (unsigned)W2, qx = (unsigned)q - t * (unsigned)W2;
+      const unsigned n = t / (unsigned)H2, qy = t - n * (unsigned)H2;
+      return ((int64_t)n * p.H + 2 * qy) * p.W + 2 * qx;
+    }
     const int qx = (int)(q % W2);
     const int64_t t = q / W2;
     const int qy = (int)(t % H2);
     const int n = (int)(t / H2);
     return ((int64_t)n * p.H + 2 * qy) * p.W + 2 * qx;
   };
+  int64_t p00_cur = 0;                  // base pixel of the quad whose loads are in flight
   auto qload = [&](int64_t q) {
-    const int64_t p00 = quad_base(q);
+    const int64_t p00 = p00_cur = quad_base(q);
 #pragma unroll
     for (int k = 0; k < 4; ++k) vq[k] = ld16((const T*)p.y + (p00 + (k >> 1) * p.W + (k & 1)) * p.PY + cg * EPV);
   };
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
     // (the quad loads of the first iteration were issued ahead of the prologue, see qload)
     int64_t q = q0;
     while (q < nq) {
-      const int64_t p00 = quad_base(q);
+      const int64_t p00 = p00_cur;
       float mx[EPV];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -618,13 +625,49 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int cg, ix, iy, n; long long o;
     dec4(dc, i, cg, o, ix, iy, n);
-    int ylo = 0, yhi = HO - 1, xlo = 0, xhi = WO - 1;
-    if (sy > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / sy) - 1); yhi = min(HO - 1, (int)ceilf((float)(iy + 1) / sy) + 1); }
-    if (sx > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / sx) - 1); xhi = min(WO - 1, (int)ceilf((float)(ix + 1) / sx) + 1); }
+    const T* b = dy + (int64_t)n * HO * WO * PDY + cg * EPV;
     float acc[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
-    const T* b = dy + (int64_t)n * HO * WO * PDY + cg * EPV;
+    if (H >= 4 && W >= 4) {
+      // The high-res rows that interpolate from low-res row iy have source coordinate in (iy-1, iy+1): an open interval
+      // of 2/sy = 4 + 2/(H-1) < 5 output rows, so it holds at most 5 of them, found among the 6 starting at
+      // floor((iy-1)/sy). Weights come from the same up_taps() as the forward pass; the 5x5 window is then read with
+      // unconditional (clamped, zero-weighted) loads that the compiler can keep in flight together, in the same
+      // (oy, ox) order as the general loop below.
+      int yb, xb; float wy[5], wx[5];
+      auto window = [&](int ic, float sc, int n_in, int n_out, int& base, float* w5) {
+        base = max(0, (int)floorf((float)(ic - 1) / sc));
+        float w6[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          int i0, i1; float l;
+          up_taps(min(base + j, n_out - 1), sc, n_in, i0, i1, l);
+          w6[j] = base + j < n_out ? (i0 == ic ? 1.f - l : 0.f) + (i1 == ic ? l : 0.f) : 0.f;
+        }
+        const bool shift = w6[0] == 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w5[j] = shift ? w6[j + 1] : w6[j];
+        base += shift ? 1 : 0;
+      };
+      window(iy, sy, H, HO, yb, wy);
+      window(ix, sx, W, WO, xb, wx);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int oy = min(yb + j, HO - 1);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int ox = min(xb + k, WO - 1);
+          const Vec16<T> g = ld16(b + ((int64_t)oy * WO + ox) * PDY);
+          const float w = wy[j] * wx[k];
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) acc[e] += w * g.get(e);
+        }
+      }
+    } else {
+    int ylo = 0, yhi = HO - 1, xlo = 0, xhi = WO - 1;
+    if (sy > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / sy) - 1); yhi = min(HO - 1, (int)ceilf((float)(iy + 1) / sy) + 1); }
+    if (sx > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / sx) - 1); xhi = min(WO - 1, (int)ceilf((float)(ix + 1) / sx) + 1); }
     for (int oy = ylo; oy <= yhi; ++oy) {
       int y0, y1; float ly;
       up_taps(oy, sy, H, y0, y1, ly);
@@ -640,6 +683,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < EPV; ++e) acc[e] += w * g.get(e);
       }
+    }
     }
     T* q = dx + o * PDX + cg * EPV;
     Vec16<T> r = accumulate ? ld16(q) : zero16<T>();
@@ -699,7 +743,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
           if (k < K) acc[k] += xv * s_w[k * C + c0 + e];
       }
     }
-    const int n = (int)(pix / hw);
+    const int n = npix < (1ll << 31) ? (int)((unsigned)pix / (unsigned)hw) : (int)(pix / hw);
     const int64_t rem = pix - n * hw;
 #pragma unroll
     for (int k = 0; k < HEAD_MAXK; ++k)

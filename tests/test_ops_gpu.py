@@ -356,7 +356,7 @@ def test_maxpool(dt):
 
 
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
-@pytest.mark.parametrize("hw", [(6, 10), (1, 1), (3, 2)])
+@pytest.mark.parametrize("hw", [(6, 10), (1, 1), (3, 2), (4, 4), (4, 7), (5, 9), (12, 6), (24, 4), (48, 48), (3, 8), (8, 3)])
 def test_upsample(dt, hw):
     h, w = hw
     n, c = 2, 64
