@@ -771,28 +771,47 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   }
   const int hw = H * W;
   const int64_t npix = (int64_t)N * hw;
-  for (int64_t pix = (int64_t)blockIdx.x * ppb + pl; pix < npix; pix += (int64_t)gridDim.x * ppb) {
-    const int n = (int)((unsigned)pix / (unsigned)hw);      // npix < 2^31 (checked on the host)
-    const int rem = (int)pix - n * hw;
-    const Vec16<T> xv = ld16(x + pix * PX + cg * EPV);
-    float g[EPV];
+  // U pixels per thread and pass, every load of a pass issued before the first use (the kernel opens the backward
+  // pass alone on the device, so its latency is the step's)
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * ppb;
+  for (int64_t pix0 = (int64_t)blockIdx.x * ppb + pl; pix0 < npix; pix0 += U * stride) {
+    Vec16<T> xv[U], ov[U];
+    float d[U][KM];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) g[e] = 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int64_t pix = pix0 + u * stride;
+      if (pix < npix) {
+        const int n = (int)((unsigned)pix / (unsigned)hw);      // npix < 2^31 (checked on the host)
+        const int rem = (int)pix - n * hw;
+        xv[u] = ld16(x + pix * PX + cg * EPV);
+        if (dx && accumulate) ov[u] = ld16(dx + pix * PDX + cg * EPV);
 #pragma unroll
-    for (int k = 0; k < KM; ++k) {
-      if (KT > 0 || k < K) {
-        const float d = dl[((int64_t)n * K + k) * hw + rem];
-        if (cg == 0) ab[k] += d;
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) { g[e] += d * wk[k][e]; aw[k][e] += d * xv.get(e); }
+        for (int k = 0; k < KM; ++k) d[u][k] = (KT > 0 || k < K) ? dl[((int64_t)n * K + k) * hw + rem] : 0.f;
       }
     }
-    if (dx) {
-      T* q = dx + pix * PDX + cg * EPV;
-      Vec16<T> o = accumulate ? ld16(q) : zero16<T>();
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) o.set(e, (accumulate ? o.get(e) : 0.f) + g[e]);
-      st16(q, o);
+    for (int u = 0; u < U; ++u) {
+      const int64_t pix = pix0 + u * stride;
+      if (pix < npix) {
+        float g[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) g[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+          if (KT > 0 || k < K) {
+            if (cg == 0) ab[k] += d[u][k];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { g[e] += d[u][k] * wk[k][e]; aw[k][e] += d[u][k] * xv[u].get(e); }
+          }
+        }
+        if (dx) {
+          Vec16<T> o;
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) o.set(e, (accumulate ? ov[u].get(e) : 0.f) + g[e]);
+          st16(dx + pix * PDX + cg * EPV, o);
+        }
+      }
     }
   }
 #pragma unroll
@@ -913,65 +932,96 @@ extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int3
 // Fused loss step of the training loop (trains.py:118-128,135-136): all heads' BCEDice
 // partial sums + IoU counts of the last head in one launch; then gradients of the
 // head-averaged loss, the loss values and the running epoch meters in a second one.
-// ws: [heads][3N+1] sums (row stride ws_stride floats) followed by 2 x uint64 IoU counts.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_step_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, float* __restrict__ ws, int ws_stride, int N, int heads) {
+// Per-block partial sums go to a slab [heads][N][LOSS_GX] x {I, P, T, BCE, iou-inter, iou-union} with plain stores (no
+// zero launch ahead, no same-address atomics, and bit-reproducible run to run); the second kernel adds the <= 64 slabs
+// of its image with one wave.
+constexpr int LOSS_GX = 64;     // most blocks per (image, head)
+__global__ __launch_bounds__(256) void loss_step_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, float* __restrict__ ws, int N, int heads) {
   const int n = blockIdx.y, hd = blockIdx.z;
   const float* xs = x + ((int64_t)hd * N + n) * per;
   const float* ts = t + (int64_t)n * per;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   unsigned ci = 0, cu = 0;
-  const bool last = hd == heads - 1;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
     const float xv = xs[i], tv = ts[i];
     const float pv = sigmoidf_(xv);
     a0 += pv * tv; a1 += pv; a2 += tv;
     a3 += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
-    if (last) { const bool a = xv > 0.f, b = tv > 0.5f; ci += (a && b) ? 1u : 0u; cu += (a || b) ? 1u : 0u; }
+    const bool a = xv > 0.f, b = tv > 0.5f; ci += (a && b) ? 1u : 0u; cu += (a || b) ? 1u : 0u;
   }
   a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o); cu += __shfl_xor(cu, o); }
-  __shared__ float s_f[4][4];
-  __shared__ unsigned s_c[4][2];
+  __shared__ float s_f[4][6];
   const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { s_f[wv][0] = a0; s_f[wv][1] = a1; s_f[wv][2] = a2; s_f[wv][3] = a3; s_c[wv][0] = ci; s_c[wv][1] = cu; }
+  if ((threadIdx.x & 63) == 0) { s_f[wv][0] = a0; s_f[wv][1] = a1; s_f[wv][2] = a2; s_f[wv][3] = a3; s_f[wv][4] = (float)ci; s_f[wv][5] = (float)cu; }
   __syncthreads();
-  if (threadIdx.x < 4) {   // one atomic per block per quantity (same-address atomics serialise)
-    float* w = ws + (size_t)hd * ws_stride;
-    const float v = s_f[0][threadIdx.x] + s_f[1][threadIdx.x] + s_f[2][threadIdx.x] + s_f[3][threadIdx.x];
-    if (threadIdx.x < 3) atomicAdd(&w[n * 3 + threadIdx.x], v);
-    else atomicAdd(&w[N * 3], v);
-  } else if (last && threadIdx.x < 6) {
-    const int k = threadIdx.x - 4;
-    unsigned long long* cnt = (unsigned long long*)(ws + (size_t)heads * ws_stride);
-    atomicAdd(&cnt[k], (unsigned long long)(s_c[0][k] + s_c[1][k] + s_c[2][k] + s_c[3][k]));
-  }
+  if (threadIdx.x < 6)    // (counts <= 256 * trip count per wave: exact in fp32 up to 2^24 per block)
+    ws[((((size_t)hd * N + n) * LOSS_GX) + blockIdx.x) * 6 + threadIdx.x] = s_f[0][threadIdx.x] + s_f[1][threadIdx.x] + s_f[2][threadIdx.x] + s_f[3][threadIdx.x];
 }
-__global__ __launch_bounds__(256) void loss_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, const float* __restrict__ ws, int ws_stride, int N, int heads, float* __restrict__ dx, float* __restrict__ loss_out, double* __restrict__ meters) {
+__global__ __launch_bounds__(256) void loss_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, const float* __restrict__ ws, int gx, int N, int heads, float* __restrict__ dx, float* __restrict__ loss_out, double* __restrict__ meters) {
   const int n = blockIdx.y, hd = blockIdx.z;
-  const float* w = ws + (size_t)hd * ws_stride;
-  if (blockIdx.x == 0 && n == 0 && hd == 0 && threadIdx.x == 0) {
-    // loss per head, their mean (trains.py:120-123), IoU of the last head (trains.py:124,128)
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const bool on = l < gx;
+  __shared__ float s_img[3];
+  __shared__ float s_acc[4][8][2];     // [wave][head] {sum of per-image dice terms, BCE sum}
+  __shared__ double s_cnt[4][2];
+  auto slab = [&](int k, int q) { return ws + ((((size_t)k * N + q) * LOSS_GX) + l) * 6; };
+  if (wv == 0) {
+    const float* w = slab(hd, n);
+    const float I = wave_sum(on ? w[0] : 0.f), P = wave_sum(on ? w[1] : 0.f), T = wave_sum(on ? w[2] : 0.f);
+    if (l == 0) { s_img[0] = I; s_img[1] = P; s_img[2] = T; }
+  }
+  // one block also owns the loss per head, their mean (trains.py:120-123) and the IoU of the last head
+  // (trains.py:124,128): its four waves take four images each per pass, all loads of a pass in flight together
+  const bool fin = blockIdx.x == 0 && n == 0 && hd == 0;
+  if (fin) {
+    double ci_s = 0.0, cu_s = 0.0;
+    for (int k = 0; k < heads; ++k) {
+      float d = 0.f, bce = 0.f;
+      for (int q0 = wv; q0 < N; q0 += 16) {
+        float v[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + 4 * u;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) v[u][c] = (on && q < N) ? slab(k, q)[c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (q0 + 4 * u < N) {
+            const float I = wave_sum(v[u][0]), P = wave_sum(v[u][1]), T = wave_sum(v[u][2]);
+            d += (2.f * I + 1e-5f) / (P + T + 1e-5f);
+            bce += wave_sum(v[u][3]);
+            if (k == heads - 1) { ci_s += (double)wave_sum(v[u][4]); cu_s += (double)wave_sum(v[u][5]); }
+          }
+        }
+      }
+      if (l == 0) { s_acc[wv][k][0] = d; s_acc[wv][k][1] = bce; }
+    }
+    if (l == 0) { s_cnt[wv][0] = ci_s; s_cnt[wv][1] = cu_s; }
+  }
+  __syncthreads();
+  if (fin && threadIdx.x == 0) {
     float mean = 0.f;
     for (int k = 0; k < heads; ++k) {
-      const float* wk = ws + (size_t)k * ws_stride;
-      float d = 0.f;
-      for (int q = 0; q < N; ++q) d += (2.f * wk[q * 3] + 1e-5f) / (wk[q * 3 + 1] + wk[q * 3 + 2] + 1e-5f);
-      const float l = 0.5f * wk[N * 3] / ((float)N * (float)per) + (1.f - d / (float)N);
-      loss_out[k] = l;
-      mean += l;
+      const float d = s_acc[0][k][0] + s_acc[1][k][0] + s_acc[2][k][0] + s_acc[3][k][0];
+      const float bce = s_acc[0][k][1] + s_acc[1][k][1] + s_acc[2][k][1] + s_acc[3][k][1];
+      const float lk = 0.5f * bce / ((float)N * (float)per) + (1.f - d / (float)N);
+      loss_out[k] = lk;
+      mean += lk;
     }
     mean /= (float)heads;
     loss_out[heads] = mean;
-    const unsigned long long* cnt = (const unsigned long long*)(ws + (size_t)heads * ws_stride);
     if (meters) {
+      const double inter = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], uni = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
       meters[0] += (double)mean;
-      meters[1] += ((double)cnt[0] + 1e-5) / ((double)cnt[1] + 1e-5);
-      meters[2] = (double)cnt[0]; meters[3] = (double)cnt[1];
+      meters[1] += (inter + 1e-5) / (uni + 1e-5);
+      meters[2] = inter; meters[3] = uni;
     }
   }
-  const float I = w[n * 3], D = w[n * 3 + 1] + w[n * 3 + 2] + 1e-5f;
+  const float I = s_img[0], D = s_img[1] + s_img[2] + 1e-5f;
   const float g = 1.f / (float)heads;
   const float kb = 0.5f / ((float)N * (float)per);
   const float num = 2.f * I + 1e-5f;
@@ -988,18 +1038,16 @@ __global__ __launch_bounds__(256) void loss_step_bwd_kernel(const float* __restr
   }
 }
 extern "C" size_t nunet_loss_step_ws_bytes(int32_t N, int32_t heads) {
-  const size_t stride = ((size_t)(3 * N + 1) + 3) / 4 * 4;
-  return (stride * heads + 4) * sizeof(float);
+  return (size_t)heads * N * LOSS_GX * 6 * sizeof(float);
 }
 extern "C" int nunet_loss_step(const float* logits, const float* target, int32_t N, int64_t per, int32_t heads, float* ws, float* dlogits, float* loss_out, double* meters, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && dlogits && loss_out && N > 0 && per > 0 && heads >= 1 && heads <= 8, "loss_step: bad args");
+  NUNET_REQUIRE(per <= (1ll << 24), "loss_step: image too large");    // per-image IoU counts stay exact in fp32
   hipStream_t st = (hipStream_t)s;
-  const int stride = (3 * N + 1 + 3) / 4 * 4;
-  { int rc = nunet_zero_async(ws, nunet_loss_step_ws_bytes(N, heads), st); if (rc) return rc; }
-  const int gx = grid_for(per, 256 * 4, 64);
+  const int gx = grid_for(per, 256, LOSS_GX);     // one element per thread up to 128x128 images: the step waits on this pair of launches
   ProfScope ps(PC_LOSS, 0, (double)N * per * heads * 16, st);
-  hipLaunchKernelGGL(loss_step_partial_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, stride, N, heads);
-  hipLaunchKernelGGL(loss_step_bwd_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, stride, N, heads, dlogits, loss_out, meters);
+  hipLaunchKernelGGL(loss_step_partial_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, N, heads);
+  hipLaunchKernelGGL(loss_step_bwd_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, gx, N, heads, dlogits, loss_out, meters);
   return nunet_check_launch("loss_step");
 }
 
