@@ -45,21 +45,67 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ par
   const float* w = params + en.src;
   const int cw = min(32, en.cin - ci0);            // real input channels in this tile (<= 0: pure padding)
   const int rw = min(32, en.cout - co0);
-  for (int i = threadIdx.x; i < 32 * 288; i += blockDim.x) {
-    const int ro = i / 288, k = i - ro * 288;      // k = ci_local*9 + tap
-    float v = 0.f;
-    if (ro < rw && k < cw * 9) v = w[((long long)(co0 + ro) * en.cin + ci0) * 9 + k];
-    s_t[ro][k] = v;
+  // full tiles (all but the first layer's): 16-byte loads and 16-byte stores (8 packed elements); the scalar
+  // form below keeps the ragged ones
+  constexpr int EPV = Tr<T>::EPV;
+  const float* wrow = w + ((long long)co0 * en.cin + ci0) * 9;
+  const bool vload = rw == 32 && cw == 32 && en.cin % 4 == 0 && ((uintptr_t)wrow & 15) == 0;
+  if (vload) {
+    for (int i = threadIdx.x; i < 32 * 72; i += blockDim.x) {
+      const int ro = i / 72, k4 = i - ro * 72;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + (long long)ro * en.cin * 9 + k4 * 4);
+      float* d = &s_t[ro][k4 * 4];
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+  } else {
+    for (int i = threadIdx.x; i < 32 * 288; i += blockDim.x) {
+      const int ro = i / 288, k = i - ro * 288;      // k = ci_local*9 + tap
+      float v = 0.f;
+      if (ro < rw && k < cw * 9) v = w[((long long)(co0 + ro) * en.cin + ci0) * 9 + k];
+      s_t[ro][k] = v;
+    }
   }
   __syncthreads();
   T* wf = arena + en.wf;
+  T* wd = en.wd >= 0 ? arena + en.wd : nullptr;
+  const bool vst = rw == 32 && en.cinpad % 8 == 0 && en.cout % 8 == 0 && ((uintptr_t)wf & 15) == 0 && ((uintptr_t)wd & 15) == 0;
+  if (vst) {
+    for (int i = threadIdx.x; i < 9 * 32 * 4; i += blockDim.x) {    // wf[tap][co][ci], ci fastest: 8 ci per thread
+      const int g = i & 3, ro = (i >> 2) & 31, tap = i >> 7;
+      if (ci0 + g * 8 < en.cinpad) {
+        T* q = wf + ((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + g * 8;
+#pragma unroll
+        for (int h = 0; h < 8 / EPV; ++h) {
+          Vec16<T> o;
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) o.set(e, s_t[ro][(g * 8 + h * EPV + e) * 9 + tap]);
+          st16(q + h * EPV, o);
+        }
+      }
+    }
+    if (wd) {
+      for (int i = threadIdx.x; i < 9 * 32 * 4; i += blockDim.x) {  // wd[8-tap][ci][co], co fastest: 8 co per thread
+        const int g = i & 3, ci = (i >> 2) & 31, tap = i >> 7;
+        if (ci < cw) {
+          T* q = wd + ((long long)(8 - tap) * en.cin + ci0 + ci) * en.cout + co0 + g * 8;
+#pragma unroll
+          for (int h = 0; h < 8 / EPV; ++h) {
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) o.set(e, s_t[g * 8 + h * EPV + e][ci * 9 + tap]);
+            st16(q + h * EPV, o);
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) {   // wf[tap][co][ci], ci fastest
     const int ci = i & 31, ro = (i >> 5) & 31, tap = i >> 10;
     if (ro < rw && ci0 + ci < en.cinpad)
       wf[((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + ci] = from_f32<T>(s_t[ro][ci * 9 + tap]);
   }
-  if (en.wd >= 0) {
-    T* wd = arena + en.wd;
+  if (wd) {
     for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) { // wd[8-tap][ci][co], co fastest
       const int ro = i & 31, ci = (i >> 5) & 31, tap = i >> 10;
       if (ro < rw && ci < cw)
