@@ -166,6 +166,89 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ s
   }
 }
 
+// The same gather as unpack_kernel, tiled like pack_kernel: one block per (layer, 32 Cout x 32 Cin tile) moves the
+// tile's [tap][co][ci] gradients through LDS with 16-byte loads along ci and writes the OIHW rows as 16-byte runs
+// (unpack_kernel's element-wise gather touches nine 128-byte lines per wave load). Blocks past the last tile own one
+// table entry each: its bias / BatchNorm vectors, or the slab sum of a 1x1 head.
+__global__ __launch_bounds__(256) void unpack_tiled_kernel(const float* __restrict__ scratch, float* __restrict__ grads, PackTab tab, UnpackTab ut) {
+  __shared__ float s_t[32][32 * 9 + 1];
+  if ((int)blockIdx.x >= tab.ntiles) {
+    const UnpackEnt en = ut.e[(int)blockIdx.x - tab.ntiles];
+    const float* dw = scratch + en.src;
+    float* g = grads + en.dst;
+    const int nw = en.cout * en.cin * en.taps;
+    if (en.nslab > 1) {                                  // 1x1 head: <= 264 elements, slabs summed in fixed order
+      const int tot = nw + en.nvec * en.cout;
+      for (int e0 = 0; e0 < tot; e0 += 256) {
+        const int ne = min(256, tot - e0);
+        const int parts = 256 / ne;
+        const int e = threadIdx.x % ne, part = threadIdx.x / ne;
+        float v = 0.f;
+        if (part < parts) {
+#pragma unroll 8
+          for (int sl = part; sl < en.nslab; sl += parts) v += dw[(long long)sl * tot + e0 + e];
+        }
+        s_t[0][threadIdx.x] = part < parts ? v : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < ne) {
+          float t = 0.f;
+          for (int q = 0; q < parts; ++q) t += s_t[0][q * ne + threadIdx.x];
+          g[e0 + threadIdx.x] = ut.accumulate ? g[e0 + threadIdx.x] + t : t;
+        }
+        __syncthreads();
+      }
+      return;
+    }
+    const float* vsrc = dw + (long long)en.taps * en.cout * en.cinpad;
+    for (int i = threadIdx.x; i < en.nvec * en.cout; i += blockDim.x) g[nw + i] = ut.accumulate ? g[nw + i] + vsrc[i] : vsrc[i];
+    return;
+  }
+  int e = 0;
+  while (e + 1 < tab.n && (int)blockIdx.x >= tab.tile0[e + 1]) ++e;
+  const PackEnt en = tab.e[e];
+  const UnpackEnt ue = ut.e[e];
+  const int t = blockIdx.x - tab.tile0[e];
+  const int nci = (en.cinpad + 31) / 32;
+  const int co0 = (t / nci) * 32, ci0 = (t % nci) * 32;
+  const int cw = min(32, en.cin - ci0), rw = min(32, en.cout - co0);
+  if (cw <= 0) return;                                   // pure padding tile
+  const float* dw = scratch + ue.src;
+  float* grow = grads + ue.dst + ((long long)co0 * en.cin + ci0) * 9;
+  const bool full = rw == 32 && cw == 32;
+  if (full && en.cinpad % 4 == 0 && ((uintptr_t)dw & 15) == 0) {
+    for (int i = threadIdx.x; i < 9 * 32 * 8; i += blockDim.x) {
+      const int c4 = i & 7, ro = (i >> 3) & 31, tap = i >> 8;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dw + ((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_t[ro][(c4 * 4 + j) * 9 + tap] = v[j];
+    }
+  } else {
+    for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) {
+      const int ci = i & 31, ro = (i >> 5) & 31, tap = i >> 10;
+      if (ro < rw && ci < cw) s_t[ro][ci * 9 + tap] = dw[((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + ci];
+    }
+  }
+  __syncthreads();
+  if (full && en.cin % 4 == 0 && ((uintptr_t)grow & 15) == 0) {
+    for (int i = threadIdx.x; i < 32 * 72; i += blockDim.x) {
+      const int ro = i / 72, k4 = i - ro * 72;
+      f32x4* q = reinterpret_cast<f32x4*>(grow + (long long)ro * en.cin * 9 + k4 * 4);
+      const float* sp = &s_t[ro][k4 * 4];
+      f32x4 v = {sp[0], sp[1], sp[2], sp[3]};
+      if (ut.accumulate) { const f32x4 o = *q; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+      *q = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < 32 * 288; i += blockDim.x) {
+      const int ro = i / 288, k = i - ro * 288;
+      if (ro < rw && k < cw * 9) {
+        float* q = grow + (long long)ro * en.cin * 9 + k;
+        *q = ut.accumulate ? *q + s_t[ro][k] : s_t[ro][k];
+      }
+    }
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------
 // Fused optimiser step: native-layout gradient scratch -> SGD(momentum, weight decay, nesterov) on the fp32 master
@@ -1365,7 +1448,16 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
   if (gx > 512) gx = 512;
   ProfScope ps(PC_UNPACK, 0, (double)P->nparams * (accumulate ? 12 : 8), st);
-  hipLaunchKernelGGL(unpack_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, gsr, grads, P->utab);
+  static int tiled = -1;
+  if (tiled < 0) { const char* e = getenv("NUNET_UNPACK_TILED"); tiled = e ? atoi(e) : 1; }
+  if (tiled) {
+    PackTab& tab = P->ptab;
+    int nt = 0;
+    for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
+    tab.tile0[tab.n] = nt; tab.ntiles = nt;
+  }
+  if (tiled) hipLaunchKernelGGL(unpack_tiled_kernel, dim3(P->ptab.ntiles + P->utab.n), dim3(256), 0, st, gsr, grads, P->ptab, P->utab);
+  else hipLaunchKernelGGL(unpack_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, gsr, grads, P->utab);
   return nunet_check_launch("unpack_grads");
 }
 
