@@ -1080,16 +1080,30 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
   // prerequisites of everything on the caller's stream, before the fork
-  if (training) CK(nunet_zero_async(stats, P->stats_floats * 4 * NUNET_BN_SUM_REPLICAS, st));
-  if (rt_of(P)->sk_ready_arena != arena) {   // K-split arrival counters: zero once, every launch leaves them zero
-    for (int l = 0; l < 5; ++l)
-      if (P->sk_floats[l] > 0) CK(nunet_zero_async(AB(arena, P->off_sk[l]), NUNET_SPLITK_COUNTER_FLOATS * 4, st));
-    rt_of(P)->sk_ready_arena = arena;
-  }
-  CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, s));
+  // NUNET_PREP_LANE=1: statistics zero + input layout run on lane 1 beside the weight pack on lane 0 instead of ahead
+  // of the fork (every conv descends from B00.conv1, which reads R_IMG, so the zeroed statistics are ordered too)
+  static int prep_lane = -1;
+  if (prep_lane < 0) { const char* e = getenv("NUNET_PREP_LANE"); prep_lane = e ? atoi(e) : 0; }
+  auto prep = [&](hipStream_t ps) -> int {
+    if (training) CK(nunet_zero_async(stats, P->stats_floats * 4 * NUNET_BN_SUM_REPLICAS, ps));
+    if (rt_of(P)->sk_ready_arena != arena) {   // K-split arrival counters: zero once, every launch leaves them zero
+      for (int l = 0; l < 5; ++l)
+        if (P->sk_floats[l] > 0) CK(nunet_zero_async(AB(arena, P->off_sk[l]), NUNET_SPLITK_COUNTER_FLOATS * 4, ps));
+      rt_of(P)->sk_ready_arena = arena;
+    }
+    CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, (nunet_stream_t)ps));
+    return NUNET_OK;
+  };
+  if (!prep_lane) CK(prep(st));
 
   Sched S; S.init(P, st, 0);
   int rc = NUNET_OK;
+  if (prep_lane) {
+    S.name("prep");
+    hipStream_t ls = S.begin(1, {}, {R_IMG, R_SK + 0, R_SK + 1, R_SK + 2, R_SK + 3, R_SK + 4});
+    rc = prep(ls);
+    S.end();
+  }
   // Measured on MI355X: repacking the weights per level on the lanes (NUNET_PACK_LANES=1) is 9 %
   // SLOWER than one pack launch ahead of the lanes; clearing the gradient scratch on a lane during
   // forward (NUNET_GS_FWD=1) is neutral. Both stay off by default.
