@@ -89,8 +89,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    force_dp = os.environ.get("NUNET_FORCE_DP") == "1"      # rehearse the N>1 code path (RCCL, three graphs) with one rank
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import nunet_amd
@@ -212,7 +214,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

@@ -46,6 +46,15 @@ class TrainStep:
         self.steps = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        # NUNET_FORCE_DP=1: take the data-parallel code path (bucketed exchange, three graphs) with any world size, so that a
+        # one-GPU box can rehearse it over RCCL with a single rank (bench.py initialises the process group)
+        self.dp = self.world > 1 or (os.environ.get("NUNET_FORCE_DP") == "1" and dist.is_initialized())
+        # Data-parallel step layout (NUNET_DP_MODE). 1 (default): one lane-faithful graph for forward + loss + the whole
+        # backward, ONE exchange of the complete gradient scratch, one graph for unpack + SGD. 0: backward cut in two phases
+        # so that bucket 0's exchange runs beside phase 2. Measured on one MI355X (single-rank RCCL group,
+        # tools/dp_probe.py): the cut costs 500 us per step (phase 1 is the anti-diagonal's dependency chain with nothing
+        # beside it, 2.71 ms vs 2.18 ms) - more than the 36.7 MB exchange it hides is expected to take on >= 4 GPUs.
+        self.dp_mode = int(os.environ.get("NUNET_DP_MODE", "1"))
         self.use_graph = use_graph
         # fused optimiser step (nunet_plan_update: scratch -> SGD -> repacked weights, one launch); the flat OIHW
         # gradients (p.grad views) are only materialised with keep_grads=True. Measured round 1: the tiled kernel takes
@@ -56,7 +65,7 @@ class TrainStep:
         self.g_fb = None
         self.g_b2 = None
         self.g_opt = None
-        self._buckets = self._grad_scratch() if self.world > 1 else None
+        self._buckets = self._grad_scratch() if self.dp else None
         for p, off in zip(self.eng.module_params, self.eng.param_off):
             p.grad = self.eng.flat_grads[off:off + p.numel()].view(p.shape)
 
@@ -112,6 +121,7 @@ class TrainStep:
         off, b0, tot = C.c_int64(), C.c_int64(), C.c_int64()
         L.check(L.lib().nunet_plan_grad_scratch(self.pl.handle, C.byref(off), C.byref(b0), C.byref(tot)), "plan_grad_scratch")
         flat = self.pl.arena[off.value:off.value + 4 * tot.value].view(torch.float32)
+        self._scratch = flat
         return flat[:b0.value], flat[b0.value:]
 
     def _exchange(self, t):
@@ -125,6 +135,15 @@ class TrainStep:
         """Data-parallel step: bucket 0 (heads + the last anti-diagonal = 75 % of the gradient bytes,
         complete after backward phase 1) is all-reduced while phase 2 runs; bucket 1 follows; unpack +
         SGD (grad_scale 1/world) run on the reduced scratch."""
+        if self.dp_mode == 1:
+            run1()
+            if run2 is not None:
+                run2()
+            h = self._exchange(self._scratch)
+            if h is not None:
+                h.wait()
+            run3()
+            return
         b0, b1 = self._buckets
         run1()
         h0 = self._exchange(b0)
@@ -136,7 +155,7 @@ class TrainStep:
         run3()
 
     def _eager_step(self):
-        if self.world > 1:
+        if self.dp:
             self._dp_step(lambda: (self._fwd_loss(), self._bwd(1)), lambda: self._bwd(2),
                           lambda: (None if self.fused_update else self._bwd(4), self._opt()))
         else:
@@ -167,7 +186,7 @@ class TrainStep:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if self.world == 1:
+        if not self.dp:
             # lane-faithful hipGraph (csrc/graph.hip): captured on a side stream, edge lists rewritten so
             # that ROCm's node->stream assignment reproduces the plan's lanes, replayed on the caller's stream
             self.g_fb = _NativeGraph(s, lambda: (self._fwd_bwd(), self._opt()))
@@ -175,6 +194,11 @@ class TrainStep:
             if iters > 0:
                 self.tune_result = self.g_fb.tune(iters)
         else:
+            if self.dp_mode == 1:
+                self.g_fb = _NativeGraph(s, lambda: (self._fwd_loss(), self._bwd(3)))
+                self.g_b2 = None
+                self.g_opt = _NativeGraph(s, lambda: (None if self.fused_update else self._bwd(4), self._opt()))
+        if self.dp and self.dp_mode != 1:
             self.g_fb = torch.cuda.CUDAGraph()          # forward + loss + backward phase 1
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):   # (the RCCL watchdog thread polls events meanwhile)
                 self._fwd_loss()
@@ -201,8 +225,8 @@ class TrainStep:
             self.x.copy_(inp, non_blocking=True)
             self.t.copy_(target, non_blocking=True)
         if self.g_fb is not None:
-            if self.world > 1:
-                self._dp_step(self.g_fb.replay, self.g_b2.replay, self.g_opt.replay)
+            if self.dp:
+                self._dp_step(self.g_fb.replay, self.g_b2.replay if self.g_b2 is not None else None, self.g_opt.replay)
             else:
                 self.g_fb.replay()
         else:

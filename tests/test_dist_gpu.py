@@ -20,8 +20,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, use_graph, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, use_graph, dp_mode, q):
+    os.environ.update(NUNET_DP_MODE=str(dp_mode), RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     import nunet_amd
     from nunet_amd.trainer import TrainStep
@@ -48,13 +48,13 @@ def _worker(rank, world, port, use_graph, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_two_rank_data_parallel_step(use_graph, synth):
+@pytest.mark.parametrize("use_graph,dp_mode", [(False, 1), (True, 1), (True, 0)])
+def test_two_rank_data_parallel_step(use_graph, dp_mode, synth):
     import nunet_amd
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, use_graph, dp_mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
