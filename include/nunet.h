@@ -276,6 +276,14 @@ int nunet_plan_backward_phase(nunet_plan* p, const float* params, const float* d
                               float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s);
 int nunet_plan_grad_scratch(const nunet_plan* p, int64_t* byte_offset, int64_t* bucket0_floats,
                             int64_t* total_floats);
+/* Exchange of the first bucket beside the rest of the backward pass, without cutting the pass in phases (replaces the
+ * bucket hooks of torch DDP over the reference's nn.DataParallel-style replica training).
+ * nunet_plan_bucket0_enable(p, 1) returns 1 when armed (0: not available for this plan, <0: error): a later backward call
+ * with phases 1|2 together then records an event as soon as the first *bucket0_floats gradients are final - as an external
+ * event record node when the call is captured into a graph. nunet_plan_bucket0_wait(p, s) makes stream `s` wait for the
+ * most recent such record: call it after launching the pass (or the graph that holds it), then all-reduce bucket 0 on `s`. */
+int nunet_plan_bucket0_enable(nunet_plan* p, int32_t on);
+int nunet_plan_bucket0_wait(nunet_plan* p, nunet_stream_t s);
 /* Fused optimiser step on the plan's buffers, replacing unpack (nunet_plan_backward_phase bit 2) + nunet_sgd_step +
  * the repack of the next forward: gradient scratch (optionally exchanged between ranks) -> torch.optim.SGD step
  * (reference trains.py:229-231; lr from device memory, momentum buffer `momentum`, weight decay, nesterov,

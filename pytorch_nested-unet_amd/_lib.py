@@ -113,6 +113,8 @@ _SIG = {
     "nunet_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "nunet_plan_backward_phase": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "nunet_plan_grad_scratch": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "nunet_plan_bucket0_enable": (_i32, [_vp, _i32]),
+    "nunet_plan_bucket0_wait": (_i32, [_vp, _vp]),
     "nunet_plan_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
     "nunet_plan_repack": (_i32, [_vp, _vp, _vp, _vp]),
     "nunet_plan_sgd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),

@@ -71,6 +71,27 @@ void graph_tag_tail(hipStream_t st, int lane) {
   if (n > g_cap.lane.size()) g_cap.lane.resize(n, lane);
 }
 
+// An event record node behind the current tail of capturing stream `st`: each replay of the graph records `ev` when the
+// tail's work is done, and streams outside the graph can wait on it (hipEventRecordWithFlags(..., hipEventRecordExternal)
+// returns "invalid argument" on this runtime, so the node is added through the graph API).
+int graph_record_external(hipStream_t st, hipEvent_t ev) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t g = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  if (hipStreamGetCaptureInfo_v2(st, &cs, &id, &g, &deps, &ndeps) != hipSuccess || cs != hipStreamCaptureStatusActive || !g) {
+    nunet_set_error("graph_record_external: stream is not capturing (%s)", hipGetErrorString(hipGetLastError()));
+    return NUNET_ELAUNCH;
+  }
+  std::vector<hipGraphNode_t> d(deps, deps + ndeps);
+  hipGraphNode_t node = nullptr;
+  hipError_t e = hipGraphAddEventRecordNode(&node, g, d.data(), d.size(), ev);
+  if (e == hipSuccess) e = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
+  if (e != hipSuccess) { nunet_set_error("graph_record_external: %s", hipGetErrorString(e)); (void)hipGetLastError(); return NUNET_ELAUNCH; }
+  return NUNET_OK;
+}
+
 bool graph_capture_active() { return g_cap.active; }
 
 extern "C" int nunet_graph_begin(nunet_stream_t s) {

@@ -488,9 +488,12 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   // NUNET_STAMPS=1 diagnostic: a 1-thread kernel after every scheduled op writes the 100 MHz wall clock,
   // so the real timeline of an (unprofiled) hipGraph replay can be read back (tools/stamp_timeline.py)
   unsigned long long* stamps;              // device, [2][STAMP_CAP]
+  hipEvent_t b0_event;                     // recorded when the first gradient bucket (phase-1 nodes + heads) is complete
+  bool b0_enabled;
   std::vector<std::string> stamp_labels[2];
 };
 void graph_tag_tail(hipStream_t st, int lane);   // graph.hip: lane bookkeeping of an active nunet_graph capture
+int graph_record_external(hipStream_t st, hipEvent_t ev);   // graph.hip: event record node at the tail of a capturing stream
 #define STAMP_CAP 512
 __global__ void stamp_kernel(unsigned long long* p) { *p = wall_clock64(); }
 struct nunet_plan;
@@ -695,6 +698,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->gs_clean_arena = nullptr;
   rt->sk_ready_arena = nullptr;
   rt->stamps = nullptr;
+  rt->b0_event = nullptr; rt->b0_enabled = false;
   rt->events_used[0] = rt->events_used[1] = 0;
   { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
   for (int l = 0; l < NLANES; ++l) {
@@ -867,6 +871,13 @@ struct Sched {
     Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0;
     for (int x : rd) if (x >= 0 && o.nrd < 12) o.rd[o.nrd++] = x;
     for (int x : wr) if (x >= 0 && o.nwr < 8) o.wr[o.nwr++] = x;
+    memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
+    o.fn = std::move(fn);
+    ops.push_back(std::move(o));
+  }
+  void add_v(int lane, int leaf, float cost, const int* rd, int nrd, std::function<int(hipStream_t)> fn) {
+    Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0;
+    for (int q = 0; q < nrd; ++q) if (rd[q] >= 0 && o.nrd < 12) o.rd[o.nrd++] = rd[q];
     memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
     o.fn = std::move(fn);
     ops.push_back(std::move(o));
@@ -1452,6 +1463,28 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       else S.add(wlane, 1, cw, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
                                 n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, wrdy[cv]}, {R_GSW + cidx}, fn);
     }
+    // "bucket 0 complete" (data-parallel exchange beside the rest of the backward pass, nunet_plan_bucket0_*): an empty op
+    // on the otherwise unused lane 4 that reads every gradient resource of the phase-1 nodes and the heads, then records
+    // the plan's event there - as an external event record node when the pass is being captured into a graph
+    if (k == k_split && (phases & 3) == 3 && rt_of(P)->b0_enabled && !P->cfg.unet && S.multi) {
+      std::vector<int> rs;
+      for (int kk = k_split; kk < nnodes; ++kk) { rs.push_back(R_GSW + 2 * kk); rs.push_back(R_GSW + 2 * kk + 1); rs.push_back(R_GSV + 2 * kk); rs.push_back(R_GSV + 2 * kk + 1); }
+      for (size_t h = 0; h < P->heads.size(); ++h) rs.push_back(R_GSV + 30 + (int)h);
+      hipEvent_t ev = rt_of(P)->b0_event;
+      for (size_t q = 0; q < rs.size(); q += 10) {
+        const bool last = q + 10 >= rs.size();
+        S.name("b0rdy");
+        S.add_v(4, 1, 0.f, rs.data() + q, (int)std::min<size_t>(10, rs.size() - q), [=](hipStream_t ls) {
+          if (!last) return (int)NUNET_OK;
+          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+          (void)hipStreamIsCapturing(ls, &cs);
+          if (cs == hipStreamCaptureStatusActive) return graph_record_external(ls, ev);
+          const hipError_t e = hipEventRecord(ev, ls);
+          if (e != hipSuccess) { nunet_set_error("plan_backward: bucket-0 event record: %s", hipGetErrorString(e)); return (int)NUNET_ELAUNCH; }
+          return (int)NUNET_OK;
+        });
+      }
+    }
   }
   if (rc == NUNET_OK) rc = S.run_ops();
   S.join();
@@ -1473,6 +1506,24 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   if (tiled) hipLaunchKernelGGL(unpack_tiled_kernel, dim3(P->ptab.ntiles + P->utab.n), dim3(256), 0, st, gsr, grads, P->ptab, P->utab);
   else hipLaunchKernelGGL(unpack_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, gsr, grads, P->utab);
   return nunet_check_launch("unpack_grads");
+}
+
+// Data-parallel exchange beside the backward pass. After nunet_plan_bucket0_enable(P, 1), a backward call that runs phases 1 and 2
+// together records the plan's event once every gradient of the first bucket (nunet_plan_grad_scratch) is complete;
+// nunet_plan_bucket0_wait makes `s` wait for the most recent such record (call it after launching the pass or the graph holding it).
+extern "C" int nunet_plan_bucket0_enable(nunet_plan* P, int32_t on) {
+  NUNET_REQUIRE(P, "plan_bucket0_enable: null plan");
+  PlanRt* rt = rt_of(P);
+  if (on && !rt->b0_event && hipEventCreateWithFlags(&rt->b0_event, hipEventDisableTiming) != hipSuccess) {
+    nunet_set_error("plan_bucket0_enable: %s", hipGetErrorString(hipGetLastError())); return NUNET_ELAUNCH;
+  }
+  rt->b0_enabled = on != 0 && !P->cfg.unet;
+  return rt->b0_enabled ? 1 : 0;     // 1: armed; 0: not available for this plan (callers exchange after the pass)
+}
+extern "C" int nunet_plan_bucket0_wait(nunet_plan* P, nunet_stream_t s) {
+  NUNET_REQUIRE(P && rt_of(P)->b0_event && rt_of(P)->b0_enabled, "plan_bucket0_wait: not enabled");
+  if (hipStreamWaitEvent((hipStream_t)s, rt_of(P)->b0_event, 0) != hipSuccess) { nunet_set_error("plan_bucket0_wait: %s", hipGetErrorString(hipGetLastError())); return NUNET_ELAUNCH; }
+  return NUNET_OK;
 }
 
 extern "C" int nunet_plan_stamps_read(nunet_plan* P, int32_t pass, uint64_t* ticks, int32_t cap, int32_t* n_out, char* labels, int32_t label_bytes) {

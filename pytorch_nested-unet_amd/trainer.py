@@ -66,6 +66,10 @@ class TrainStep:
         self.g_b2 = None
         self.g_opt = None
         self._buckets = self._grad_scratch() if self.dp else None
+        self._b0_armed = False
+        if self.dp and self.dp_mode == 2:
+            self._b0_armed = L.lib().nunet_plan_bucket0_enable(self.pl.handle, 1) == 1
+            self._comm = torch.cuda.Stream()
         for p, off in zip(self.eng.module_params, self.eng.param_off):
             p.grad = self.eng.flat_grads[off:off + p.numel()].view(p.shape)
 
@@ -135,13 +139,27 @@ class TrainStep:
         """Data-parallel step: bucket 0 (heads + the last anti-diagonal = 75 % of the gradient bytes,
         complete after backward phase 1) is all-reduced while phase 2 runs; bucket 1 follows; unpack +
         SGD (grad_scale 1/world) run on the reduced scratch."""
-        if self.dp_mode == 1:
+        if self.dp_mode in (1, 2):
             run1()
             if run2 is not None:
                 run2()
-            h = self._exchange(self._scratch)
-            if h is not None:
-                h.wait()
+            if self.dp_mode == 2 and self._b0_armed and dist.get_backend(self.pg) != "gloo":
+                # bucket 0 starts on the side stream as soon as the pass (still running) has recorded "bucket 0
+                # complete"; bucket 1 follows the pass on the caller's stream
+                b0, b1 = self._buckets
+                cur = torch.cuda.current_stream()
+                L.check(L.lib().nunet_plan_bucket0_wait(self.pl.handle, self._comm.cuda_stream), "plan_bucket0_wait")
+                with torch.cuda.stream(self._comm):
+                    h0 = dist.all_reduce(b0, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                h1 = dist.all_reduce(b1, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                with torch.cuda.stream(self._comm):
+                    h0.wait()
+                cur.wait_stream(self._comm)
+                h1.wait()
+            else:
+                h = self._exchange(self._scratch)
+                if h is not None:
+                    h.wait()
             run3()
             return
         b0, b1 = self._buckets
@@ -156,7 +174,9 @@ class TrainStep:
 
     def _eager_step(self):
         if self.dp:
-            self._dp_step(lambda: (self._fwd_loss(), self._bwd(1)), lambda: self._bwd(2),
+            one_pass = self.dp_mode in (1, 2)     # the bucket-0 event is recorded by a pass that runs both phases together
+            self._dp_step((lambda: (self._fwd_loss(), self._bwd(3))) if one_pass else (lambda: (self._fwd_loss(), self._bwd(1))),
+                          None if one_pass else (lambda: self._bwd(2)),
                           lambda: (None if self.fused_update else self._bwd(4), self._opt()))
         else:
             self._fwd_bwd()
@@ -194,11 +214,11 @@ class TrainStep:
             if iters > 0:
                 self.tune_result = self.g_fb.tune(iters)
         else:
-            if self.dp_mode == 1:
+            if self.dp_mode in (1, 2):
                 self.g_fb = _NativeGraph(s, lambda: (self._fwd_loss(), self._bwd(3)))
                 self.g_b2 = None
                 self.g_opt = _NativeGraph(s, lambda: (None if self.fused_update else self._bwd(4), self._opt()))
-        if self.dp and self.dp_mode != 1:
+        if self.dp and self.dp_mode not in (1, 2):
             self.g_fb = torch.cuda.CUDAGraph()          # forward + loss + backward phase 1
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):   # (the RCCL watchdog thread polls events meanwhile)
                 self._fwd_loss()
