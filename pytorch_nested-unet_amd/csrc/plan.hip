@@ -1268,6 +1268,83 @@ extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, 
 
 // Optimiser step straight from the gradient scratch (unpack_sgd_kernel): replaces nunet_plan_backward_phase bit 2 +
 // nunet_sgd_step; the weights are repacked by the next nunet_plan_forward as usual.
+// unpack_tiled_kernel with the optimiser step as the epilogue of its store phase: the tile's gradients meet the OIHW
+// parameters and momentum as 16-byte runs, the flat gradient arena is written only when the caller wants it.
+__global__ __launch_bounds__(256) void unpack_sgd_tiled_kernel(UpdP u, PackTab tab, UnpackTab ut) {
+  __shared__ float s_t[32][32 * 9 + 1];
+  const float lr = u.lr[0];
+  auto step1 = [&](long long idx, float g) {
+    g *= u.gscale;
+    if (u.grads) u.grads[idx] = g;
+    float m = u.mom[idx];
+    const float pn = sgd_one(u.params[idx], g, &m, u, lr);
+    u.mom[idx] = m; u.params[idx] = pn;
+  };
+  if ((int)blockIdx.x >= tab.ntiles) {
+    const UnpackEnt en = ut.e[(int)blockIdx.x - tab.ntiles];
+    const float* dw = u.scratch + en.src;
+    const int nw = en.cout * en.cin * en.taps;
+    if (en.nslab > 1) {                                  // 1x1 head: slabs summed in fixed order
+      const int tot = nw + en.nvec * en.cout;
+      for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        float g = 0.f;
+        for (int sl = 0; sl < en.nslab; ++sl) g += dw[(long long)sl * tot + e];
+        step1(en.dst + e, g);
+      }
+      return;
+    }
+    const float* vsrc = dw + (long long)en.taps * en.cout * en.cinpad;
+    for (int i = threadIdx.x; i < en.nvec * en.cout; i += blockDim.x) step1(en.dst + nw + i, vsrc[i]);
+    return;
+  }
+  int e = 0;
+  while (e + 1 < tab.n && (int)blockIdx.x >= tab.tile0[e + 1]) ++e;
+  const PackEnt en = tab.e[e];
+  const UnpackEnt ue = ut.e[e];
+  const int t = blockIdx.x - tab.tile0[e];
+  const int nci = (en.cinpad + 31) / 32;
+  const int co0 = (t / nci) * 32, ci0 = (t % nci) * 32;
+  const int cw = min(32, en.cin - ci0), rw = min(32, en.cout - co0);
+  if (cw <= 0) return;
+  const float* dw = u.scratch + ue.src;
+  const long long row0 = ue.dst + ((long long)co0 * en.cin + ci0) * 9;
+  const bool full = rw == 32 && cw == 32;
+  if (full && en.cinpad % 4 == 0 && ((uintptr_t)dw & 15) == 0) {
+    for (int i = threadIdx.x; i < 9 * 32 * 8; i += blockDim.x) {
+      const int c4 = i & 7, ro = (i >> 3) & 31, tap = i >> 8;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dw + ((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_t[ro][(c4 * 4 + j) * 9 + tap] = v[j];
+    }
+  } else {
+    for (int i = threadIdx.x; i < 9 * 32 * 32; i += blockDim.x) {
+      const int ci = i & 31, ro = (i >> 5) & 31, tap = i >> 10;
+      if (ro < rw && ci < cw) s_t[ro][ci * 9 + tap] = dw[((long long)tap * en.cout + co0 + ro) * en.cinpad + ci0 + ci];
+    }
+  }
+  __syncthreads();
+  const bool al = ((uintptr_t)(u.params + row0) & 15) == 0 && ((uintptr_t)(u.mom + row0) & 15) == 0 && (!u.grads || ((uintptr_t)(u.grads + row0) & 15) == 0);
+  if (full && en.cin % 4 == 0 && al) {
+    for (int i = threadIdx.x; i < 32 * 72; i += blockDim.x) {
+      const int ro = i / 72, k4 = i - ro * 72;
+      const long long idx = row0 + (long long)ro * en.cin * 9 + k4 * 4;
+      const float* sp = &s_t[ro][k4 * 4];
+      f32x4 g = {sp[0] * u.gscale, sp[1] * u.gscale, sp[2] * u.gscale, sp[3] * u.gscale};
+      f32x4 pv = *reinterpret_cast<const f32x4*>(u.params + idx), mv = *reinterpret_cast<const f32x4*>(u.mom + idx);
+      if (u.grads) *reinterpret_cast<f32x4*>(u.grads + idx) = g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float m = mv[j]; pv[j] = sgd_one(pv[j], g[j], &m, u, lr); mv[j] = m; }
+      *reinterpret_cast<f32x4*>(u.mom + idx) = mv;
+      *reinterpret_cast<f32x4*>(u.params + idx) = pv;
+    }
+  } else {
+    for (int i = threadIdx.x; i < 32 * 288; i += blockDim.x) {
+      const int ro = i / 288, k = i - ro * 288;
+      if (ro < rw && k < cw * 9) step1(row0 + (long long)ro * en.cin * 9 + k, s_t[ro][k]);
+    }
+  }
+}
+
 extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
                               int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s) {
   NUNET_REQUIRE(P && params && momentum && arena && lr_dev, "plan_sgd: null pointer");
@@ -1278,7 +1355,17 @@ extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, voi
   int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
   if (gx > 512) gx = 512;
   ProfScope ps(PC_SGD, 0, (double)P->nparams * (grads ? 24.0 : 20.0), st);
-  hipLaunchKernelGGL(unpack_sgd_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, u, P->utab);
+  static int tiled = -1;
+  if (tiled < 0) { const char* e = getenv("NUNET_UNPACK_TILED"); tiled = e ? atoi(e) : 1; }
+  if (tiled) {
+    PackTab& tab = P->ptab;
+    int nt = 0;
+    for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
+    tab.tile0[tab.n] = nt; tab.ntiles = nt;
+    hipLaunchKernelGGL(unpack_sgd_tiled_kernel, dim3(nt + P->utab.n), dim3(256), 0, st, u, tab, P->utab);
+  } else {
+    hipLaunchKernelGGL(unpack_sgd_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, u, P->utab);
+  }
   return nunet_check_launch("plan_sgd");
 }
 
