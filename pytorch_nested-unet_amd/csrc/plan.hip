@@ -281,15 +281,29 @@ __global__ __launch_bounds__(512) void update_kernel(UpdP u, T* __restrict__ are
     const UnpackEnt en = ut.e[u.nconv + (int)blockIdx.x - tab.ntiles];
     const float* dw = u.scratch + en.src;
     const int tot = en.cout * en.cin * en.taps + en.nvec * en.cout;
-    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-      float g = 0.f;
-      for (int sl = 0; sl < en.nslab; ++sl) g += dw[(long long)sl * tot + e];
-      g *= u.gscale;
-      const long long idx = en.dst + e;
-      if (u.grads) u.grads[idx] = g;
-      float m = u.mom[idx];
-      const float pn = sgd_one(u.params[idx], g, &m, u, lr);
-      u.mom[idx] = m; u.params[idx] = pn;
+    const int B = blockDim.x;     // B/ne threads share an element's slabs (see unpack_sgd_tiled_kernel), fixed order
+    for (int e0 = 0; e0 < tot; e0 += B) {
+      const int ne = min(B, tot - e0);
+      const int parts = B / ne;
+      const int el = threadIdx.x % ne, part = threadIdx.x / ne;
+      float v = 0.f;
+      if (part < parts) {
+#pragma unroll 8
+        for (int sl = part; sl < en.nslab; sl += parts) v += dw[(long long)sl * tot + e0 + el];
+      }
+      (&s_t[0][0])[threadIdx.x] = part < parts ? v : 0.f;
+      __syncthreads();
+      if ((int)threadIdx.x < ne) {
+        float g = 0.f;
+        for (int q = 0; q < parts; ++q) g += (&s_t[0][0])[q * ne + threadIdx.x];
+        g *= u.gscale;
+        const long long idx = en.dst + e0 + threadIdx.x;
+        if (u.grads) u.grads[idx] = g;
+        float m = u.mom[idx];
+        const float pn = sgd_one(u.params[idx], g, &m, u, lr);
+        u.mom[idx] = m; u.params[idx] = pn;
+      }
+      __syncthreads();
     }
     return;
   }
@@ -1284,12 +1298,27 @@ __global__ __launch_bounds__(256) void unpack_sgd_tiled_kernel(UpdP u, PackTab t
     const UnpackEnt en = ut.e[(int)blockIdx.x - tab.ntiles];
     const float* dw = u.scratch + en.src;
     const int nw = en.cout * en.cin * en.taps;
-    if (en.nslab > 1) {                                  // 1x1 head: slabs summed in fixed order
+    if (en.nslab > 1) {
+      // 1x1 head: 256/ne threads share an element's slabs (a single thread walking all 256 slabs is a chain of 256
+      // dependent-latency loads: that loop alone made the earlier fused kernels 100 us long), fixed summation order
       const int tot = nw + en.nvec * en.cout;
-      for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-        float g = 0.f;
-        for (int sl = 0; sl < en.nslab; ++sl) g += dw[(long long)sl * tot + e];
-        step1(en.dst + e, g);
+      for (int e0 = 0; e0 < tot; e0 += 256) {
+        const int ne = min(256, tot - e0);
+        const int parts = 256 / ne;
+        const int e = threadIdx.x % ne, part = threadIdx.x / ne;
+        float v = 0.f;
+        if (part < parts) {
+#pragma unroll 8
+          for (int sl = part; sl < en.nslab; sl += parts) v += dw[(long long)sl * tot + e0 + e];
+        }
+        s_t[0][threadIdx.x] = part < parts ? v : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < ne) {
+          float g = 0.f;
+          for (int q = 0; q < parts; ++q) g += s_t[0][q * ne + threadIdx.x];
+          step1(en.dst + e0 + threadIdx.x, g);
+        }
+        __syncthreads();
       }
       return;
     }

@@ -56,10 +56,11 @@ class TrainStep:
         # beside it, 2.71 ms vs 2.18 ms) - more than the 36.7 MB exchange it hides is expected to take on >= 4 GPUs.
         self.dp_mode = int(os.environ.get("NUNET_DP_MODE", "1"))
         self.use_graph = use_graph
-        # fused optimiser step (nunet_plan_update: scratch -> SGD -> repacked weights, one launch); the flat OIHW
-        # gradients (p.grad views) are only materialised with keep_grads=True. Measured round 1: the tiled kernel takes
-        # 152 us against 101 us for unpack + sgd + pack as three streaming launches, so it is opt-in for now.
-        self.fused_update = int(os.environ.get("NUNET_FUSED_UPDATE", "0")) if fused_update is None else int(fused_update)   # 0 three streaming launches (default, fastest), 1 one tile kernel incl. repack, 2 unpack+sgd fused
+        # optimiser step layout: 0 = unpack, SGD, (next forward's) pack as three streaming launches; 2 (default) = unpack
+        # with the SGD step as its epilogue (nunet_plan_sgd, 46 us against 59 us for the pair); 1 = one tile kernel that
+        # also repacks the weights (nunet_plan_update). The flat OIHW gradients (p.grad views) are materialised with
+        # keep_grads=True in the fused layouts.
+        self.fused_update = int(os.environ.get("NUNET_FUSED_UPDATE", "2")) if fused_update is None else int(fused_update)   
         self.keep_grads = keep_grads
         self._packed = False          # the arena's packed weights match the fp32 parameters
         self.g_fb = None
