@@ -59,7 +59,8 @@ class TrainStep:
         # optimiser step layout: 0 = unpack, SGD, (next forward's) pack as three streaming launches; 2 (default) = unpack
         # with the SGD step as its epilogue (nunet_plan_sgd, 46 us against 59 us for the pair); 1 = one tile kernel that
         # also repacks the weights (nunet_plan_update). The flat OIHW gradients (p.grad views) are materialised with
-        # keep_grads=True in the fused layouts.
+        # keep_grads=True in the fused layouts, where they hold the rank-MEAN gradient (grad_scale = 1/world applied, as
+        # DistributedDataParallel leaves p.grad); layout 0 leaves the rank-SUM there and scales inside the SGD kernel.
         self.fused_update = int(os.environ.get("NUNET_FUSED_UPDATE", "2")) if fused_update is None else int(fused_update)   
         self.keep_grads = keep_grads
         self._packed = False          # the arena's packed weights match the fp32 parameters

@@ -42,6 +42,8 @@ def _worker(rank, world, port, use_graph, dp_mode, q):
     torch.cuda.synchronize()
     w = m.conv0_4.conv2.weight.detach().cpu().clone()
     g = m.conv0_4.conv2.weight.grad.detach().cpu().clone()     # summed over ranks by the all-reduce
+    if ts.fused_update:
+        g = g * world          # the fused optimiser layouts leave the rank-MEAN gradient in p.grad (grad_scale applied)
     ts.step(x, t)
     torch.cuda.synchronize()
     q.put((rank, w.numpy(), g.numpy(), m.conv3_1.conv1.weight.detach().cpu().numpy(), ts.epoch_stats()))
