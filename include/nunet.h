@@ -47,18 +47,24 @@ const char* nunet_last_error(void);
 /* 3x3 convolution, pad 1, stride 1 (nn.Conv2d(ci,co,3,padding=1),           */
 /* reference finished/archs1.py:18,20) and its two gradients.                */
 /* ------------------------------------------------------------------------ */
-/* Per-channel reduction buffers that thousands of workgroups add to (BatchNorm backward sums) are
- * replicated: a workgroup adds to replica (its index mod r), r = clamp(256 / C, 1, NUNET_BN_SUM_REPLICAS),
- * the consumer sums those r replicas (replica stride 2*C floats). Same-address global atomics serialise at ~12 ns each on MI355X; 576 workgroups on one
- * address cost 7 us at the end of a 14 us kernel. */
+/* Per-channel reduction buffers that hundreds of workgroups add to (BatchNorm statistics, BatchNorm-backward sums)
+ * are ORDER-INDEPENDENT fixed-point accumulators: one value = NUNET_FX_WORDS int64 words (hi, lo),
+ * value = hi * 2^-20 + lo * 2^-60, added with integer atomics (which commute: the total is bit-identical from run to
+ * run, unlike fp32 atomics whose result depends on arrival order). A buffer is
+ *     int64_t acc[r][2][C][NUNET_FX_WORDS],  r = clamp(256 / C, 1, NUNET_BN_SUM_REPLICAS) replicas actually used
+ * (a workgroup adds to replica (its index mod r): same-address atomics serialise at ~12 ns each on MI355X, 576
+ * workgroups on one address cost 7 us at the end of a 14 us kernel); consumers sum the r replicas exactly.
+ * Size it for NUNET_BN_SUM_REPLICAS replicas and zero it before the producing launch. */
 #define NUNET_BN_SUM_REPLICAS 8
-#define NUNET_SPLITK_COUNTER_FLOATS 256
+#define NUNET_FX_WORDS 2
+
+enum { NUNET_TF_NONE = 0, NUNET_TF_BN_RELU = 1, NUNET_TF_BN_RELU_BWD = 2 };
 
 typedef struct {
   int32_t dtype;
   int32_t N, H, W;
   /* input = channel concat of up to two NHWC sources (zero-copy torch.cat,
-   * reference finished/archs1.py:116-131) */
+   * reference finished/archs1.py:116-131); C0, C1 multiples of the 64-byte channel chunk (32 / 16 for 2- / 4-byte types) */
   const void* src0; int32_t C0, P0;
   const void* src1; int32_t C1, P1; /* C1 = 0: unused */
   const void* wpack;                /* [9][Cout][Cin], dtype; Cin = C0+C1 */
@@ -69,18 +75,40 @@ typedef struct {
   int32_t acc_slot_w;               /* width (channels) of one dst0 slot, 0 = D0 */
   uint32_t acc0_mask;               /* bit k: dst0 slot k accumulates (+=) */
   int32_t acc1;                     /* dst1 accumulates */
-  float* stats;                     /* [NUNET_BN_SUM_REPLICAS][2][Cout] fp32, pre-zeroed: += sum(y-b), sum((y-b)^2); or NULL */
+  int64_t* stats;                   /* fixed-point sums [rep][2][Cout] (see above), pre-zeroed: += sum(y-b), sum((y-b)^2); or NULL */
   float* splitk_ws;                 /* optional fp32 scratch: lets grid-starved layers split the contraction over */
-  int64_t splitk_ws_floats;         /* workgroups: NUNET_SPLITK_COUNTER_FLOATS arrival counters (ZERO before the first use;
-                                     * every launch leaves them zero) + S slabs of N*H*W*Cout floats. NULL: never split */
+  int64_t splitk_ws_floats;         /* workgroups: up to S slabs of N*H*W*Cout floats, summed in fixed order. NULL: never split */
   /* Optional fused BatchNorm+ReLU backward REDUCE (used for the dgrad of a block's second conv, whose
    * output is the gradient entering the first conv's BN, archs1.py:18-19): with z = relu(bn(bn_y)),
    * dz = (z > 0) ? dst0 : 0, bn_sums[c] += sum dz, bn_sums[Cout + c] += sum dz * xhat. Needs D1 == 0,
    * Q0 == D0, no accumulation. NULL bn_y: off (nunet_bn_relu_bwd_reduce does the same as its own pass). */
   const void* bn_y; int32_t bn_py;  /* raw output of the BN's conv, [N*H*W][bn_py] */
-  const float* bn_mean_invstd;      /* [2][Cout] saved by nunet_bn_relu_fwd */
+  const float* bn_mean_invstd;      /* [2][Cout] saved by the BN forward */
   const float* bn_gamma; const float* bn_beta;
-  float* bn_sums;                   /* [NUNET_BN_SUM_REPLICAS][2][Cout], pre-zeroed (same buffer nunet_bn_relu_bwd_apply reads) */
+  int64_t* bn_sums;                 /* fixed-point sums [rep][2][Cout], pre-zeroed */
+  /* Optional INPUT TRANSFORM, applied between the global load and the LDS write of the input tile (single source:
+   * C1 == 0), so that the tensor between a BatchNorm and the conv that consumes it never makes its own round trip
+   * through HBM on the dependency chain:
+   *   NUNET_TF_BN_RELU      x = relu(bn(src0)): nn.BatchNorm2d + nn.ReLU between the two convs of a VGGBlock
+   *                         (archs1.py:23-30). Training: batch statistics from tf_fx (the sums the producing conv took
+   *                         in its epilogue); workgroup 0 also writes tf_mean_invstd and updates the running statistics
+   *                         / num_batches_tracked (momentum tf_momentum). Eval: running statistics.
+   *   NUNET_TF_BN_RELU_BWD  x = BatchNorm+ReLU backward of src0 (= dL/d relu(bn(tf_y))):
+   *                         x = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)), sums from tf_fx, saved
+   *                         statistics from tf_mean_invstd; workgroup 0 writes tf_dbeta = sum dz, tf_dgamma =
+   *                         sum dz*xhat, tf_dbias = 0 (a conv bias in front of a BatchNorm has zero gradient).
+   * tf_store (optional): the transformed tensor [N*H*W][tf_ps] is also written out (each pixel once, by the
+   * workgroups of Cout-tile 0) for the weight-gradient kernel. */
+  int32_t in_tf;
+  int32_t tf_training;
+  const void* tf_y; int32_t tf_py;
+  const int64_t* tf_fx;
+  const float* tf_gamma; const float* tf_beta; const float* tf_conv_bias;
+  float* tf_running_mean; float* tf_running_var; int64_t* tf_nbt;
+  float* tf_mean_invstd;
+  float tf_momentum, tf_eps;
+  float* tf_dgamma; float* tf_dbeta; float* tf_dbias;
+  void* tf_store; int32_t tf_ps;
 } nunet_conv_desc;
 
 /* y = conv(cat(src0,src1)) + bias. Also used as dgrad with the flipped,
@@ -93,13 +121,23 @@ typedef struct {
   const void* src0; int32_t C0, P0; /* forward input (concat) */
   const void* src1; int32_t C1, P1;
   const void* dy;   int32_t Cout, PY; /* grad wrt raw conv output */
-  float* dw;                        /* [9][Cout][Cin] fp32, atomically accumulated */
+  float* dw;                        /* slab 0 of the K-split: [9][Cout][Cin] fp32; slab s at dw + s * slab_stride */
+  int64_t slab_stride;              /* floats between slabs (0: 9*Cout*Cin) */
+  int32_t max_slabs;                /* capacity of the caller's slab buffer (0: unlimited, i.e. nunet_conv3x3_wgrad_slabs of it) */
+  int32_t target_wgs;               /* workgroups the launch should reach through the K-split (0: 256) */
 } nunet_wgrad_desc;
 
-/* dw[tap][co][ci] += sum_p dy[p][co] * x[p+tap][ci] */
+/* Partial weight gradients: the contraction over pixels is split into nunet_conv3x3_wgrad_slabs(d) slices; slice s
+ * writes dw_s[tap][co][ci] = sum_{p in slice s} dy[p][co] * x[p+tap][ci] to slab s with plain stores (every slab
+ * fully overwritten; no atomics, no pre-zeroing). The caller sums the slabs in a fixed order (nunet_wgrad_reduce,
+ * or the plan's batched reduce), which makes the gradient bit-reproducible. */
+int32_t nunet_conv3x3_wgrad_slabs(const nunet_wgrad_desc* d);
 int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s);
 /* Two independent problems (the two convolutions of one VGGBlock, archs1.py:18,20) in ONE launch. */
 int nunet_conv3x3_wgrad_pair(const nunet_wgrad_desc* a, const nunet_wgrad_desc* b, nunet_stream_t stream);
+/* out[i] (+)= sum_s slabs[s * slab_stride + i], i < n (n, slab_stride multiples of 4; 16-byte aligned) */
+int nunet_wgrad_reduce(const float* slabs, int64_t slab_stride, int32_t nslabs, int64_t n, float* out,
+                       int32_t accumulate, nunet_stream_t s);
 
 /* OIHW fp32 -> packed KRSC `dtype`:
  *   wf[tap][co][ci]      (forward;  ci padded with zeros up to cin_pad)
@@ -118,7 +156,7 @@ typedef struct {
   int32_t N, H, W, C;
   const void* y; int32_t PY;        /* conv output stored WITHOUT its bias */
   const float* conv_bias;           /* [C] or NULL: bias of the producing conv, folded in here */
-  const float* stats;               /* [NUNET_BN_SUM_REPLICAS][2][C] sums / sums of squares of the stored y (training) */
+  const int64_t* stats;             /* fixed-point sums / sums of squares of the stored y (training), as the conv's `stats` */
   const float* gamma; const float* beta;
   float* running_mean; float* running_var; int64_t* num_batches_tracked;
   float* save_mean_invstd;          /* [2][C] out (training): mean of the stored y, 1/sqrt(var+eps) */
@@ -136,9 +174,9 @@ typedef struct {
   const void* y;  int32_t PY;
   const float* mean_invstd;         /* [2][C] */
   const float* gamma; const float* beta;
-  float* sums;                      /* [NUNET_BN_SUM_REPLICAS][2][C] scratch, zeroed by caller: sum dz, sum dz*xhat */
-  float* dgamma; float* dbeta;      /* [C] += */
-  float* dbias;                     /* [C] += sum dy (conv bias grad) */
+  int64_t* sums;                    /* fixed-point sums [rep][2][C], zeroed by caller: sum dz, sum dz*xhat */
+  float* dgamma; float* dbeta;      /* [C] = sum dz*xhat, sum dz (written by _apply) */
+  float* dbias;                     /* [C] = 0: the conv bias in front of a BatchNorm has gradient sum(dy) == 0 */
   void* dy; int32_t PDY;            /* grad wrt raw conv output */
 } nunet_bn_bwd_desc;
 int nunet_bn_relu_bwd_reduce(const nunet_bn_bwd_desc* d, nunet_stream_t s);
@@ -180,7 +218,7 @@ int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, in
 /* ------------------------------------------------------------------------ */
 /* BCEDiceLoss (losses.py:103-117), iou_score (metrics.py:6-18)              */
 /* ------------------------------------------------------------------------ */
-/* sums: [N][3] (sum p*t, sum p, sum t) + [1] (sum bce), zeroed here. loss: [1]. */
+/* ws: [N][3] (sum p*t, sum p, sum t) + [1] (sum bce) + per-block partial slabs (summed in fixed order). loss: [1]. */
 size_t nunet_bce_dice_ws_bytes(int32_t N);
 int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int64_t per_sample,
                        float* ws, float* loss, nunet_stream_t s);

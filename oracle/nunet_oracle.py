@@ -40,6 +40,21 @@ def _to_t(v, dtype):
     return t.to(dtype) if t.is_floating_point() else t
 
 
+class _RoundST(torch.autograd.Function):
+    """Storage-rounding emulation: the value is rounded to `dt` on the way forward and (round_grad) the gradient on the
+    way back - what a tensor (and the gradient tensor of the same shape) suffers when the HIP path keeps it in 16-bit
+    storage between two kernels. The arithmetic around it stays in the oracle's own precision."""
+
+    @staticmethod
+    def forward(ctx, x, dt, round_grad):
+        ctx.dt, ctx.rg = dt, round_grad
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dt).to(g.dtype) if ctx.rg else g), None, None
+
+
 class OracleNet:
     """Functional NestedUNet over a reference-format state dict.
 
@@ -49,7 +64,12 @@ class OracleNet:
     """
 
     def __init__(self, state, num_classes=1, input_channels=3, deep_supervision=False,
-                 dtype=torch.float32):
+                 dtype=torch.float32, storage=None):
+        # storage (torch.bfloat16 / torch.float16 / None): emulate the HIP path's 16-bit STORAGE points (packed conv
+        # weights, raw conv outputs without bias, activations, upsampled / pooled tensors, and the gradients of all of
+        # these) inside an fp32/fp64 evaluation, so that reduced-precision runs can be checked against "the same
+        # roundings, exact arithmetic" instead of only against the unrounded network
+        self.storage = storage
         self.ncls = num_classes
         self.cin = input_channels
         self.ds = bool(deep_supervision)
@@ -91,7 +111,10 @@ class OracleNet:
     def _conv_bn_relu(self, x, prefix, k):
         w = self.params["%sconv%d.weight" % (prefix, k)]
         b = self.params["%sconv%d.bias" % (prefix, k)]
-        y = F.conv2d(x, w, b, padding=1)                                  # archs1.py:18,20
+        if self.storage is None:
+            y = F.conv2d(x, w, b, padding=1)                              # archs1.py:18,20
+        else:   # packed weights are rounded, the conv output is stored without its bias (the BatchNorm absorbs it)
+            y = self._r(F.conv2d(x, _RoundST.apply(w, self.storage, False), None, padding=1)) + b.view(1, -1, 1, 1)
         g = self.params["%sbn%d.weight" % (prefix, k)]
         be = self.params["%sbn%d.bias" % (prefix, k)]
         rm = self.buffers["%sbn%d.running_mean" % (prefix, k)]
@@ -99,7 +122,10 @@ class OracleNet:
         if self.training:
             self.buffers["%sbn%d.num_batches_tracked" % (prefix, k)] += 1
         y = F.batch_norm(y, rm, rv, g, be, self.training, BN_MOMENTUM, BN_EPS)  # archs1.py:19,21
-        return F.relu(y)                                                  # archs1.py:17
+        return self._r(F.relu(y))                                         # archs1.py:17
+
+    def _r(self, t):
+        return t if self.storage is None else _RoundST.apply(t, self.storage, True)
 
     def _block(self, x, i, j):
         p = "conv%d_%d." % (i, j)
@@ -109,12 +135,14 @@ class OracleNet:
     def __call__(self, inp):
         x = {}
         inp = inp.to(self.dtype)
+        if self.storage is not None:
+            inp = inp.to(self.storage).to(self.dtype)
         for (i, j) in _nodes():
             if j == 0:
-                src = inp if i == 0 else F.max_pool2d(x[(i - 1, 0)], 2, 2)      # archs1.py:82
+                src = inp if i == 0 else self._r(F.max_pool2d(x[(i - 1, 0)], 2, 2))      # archs1.py:82
             else:
-                up = F.interpolate(x[(i + 1, j - 1)], scale_factor=2, mode="bilinear",
-                                   align_corners=True)                         # archs1.py:83
+                up = self._r(F.interpolate(x[(i + 1, j - 1)], scale_factor=2, mode="bilinear",
+                                           align_corners=True))                # archs1.py:83
                 src = torch.cat([x[(i, k)] for k in range(j)] + [up], 1)       # archs1.py:116-131
             x[(i, j)] = self._block(src, i, j)
         self.features = x

@@ -20,6 +20,30 @@ TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 _vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 BN_SUM_REPLICAS = 8        # NUNET_BN_SUM_REPLICAS in include/nunet.h
+FX_WORDS = 2               # NUNET_FX_WORDS: int64 words of one fixed-point accumulator (hi * 2^-20 + lo * 2^-60)
+TF_NONE, TF_BN_RELU, TF_BN_RELU_BWD = 0, 1, 2
+
+
+def fx_zeros(c, device):
+    """A zeroed fixed-point per-channel sum buffer [REPLICAS][2][c][FX_WORDS] (int64), see include/nunet.h."""
+    return torch.zeros(BN_SUM_REPLICAS * 2 * c * FX_WORDS, dtype=torch.int64, device=device)
+
+
+def fx_decode(buf, c):
+    """[2*c] float64 totals of a fixed-point sum buffer (exact integer sum over the replicas first)."""
+    w = buf.detach().cpu().view(BN_SUM_REPLICAS, 2 * c, FX_WORDS).sum(0)
+    return w[:, 0].double() * 2.0 ** -20 + w[:, 1].double() * 2.0 ** -60
+
+
+def fx_encode(values, c, device):
+    """Fixed-point buffer holding `values` ([2*c] float64) in replica 0 (what a producing kernel would have left)."""
+    v = values.detach().cpu().double().reshape(2 * c) * 2.0 ** 20
+    hi = torch.floor(v)
+    lo = torch.floor((v - hi) * 2.0 ** 40)
+    buf = torch.zeros(BN_SUM_REPLICAS, 2 * c, FX_WORDS, dtype=torch.int64)
+    buf[0, :, 0] = hi.to(torch.int64)
+    buf[0, :, 1] = lo.to(torch.int64)
+    return buf.reshape(-1).to(device)
 
 
 class ConvDesc(C.Structure):
@@ -31,7 +55,12 @@ class ConvDesc(C.Structure):
                 ("dst1", _vp), ("D1", _i32), ("Q1", _i32),
                 ("acc_slot_w", _i32), ("acc0_mask", _u32), ("acc1", _i32),
                 ("stats", _vp), ("splitk_ws", _vp), ("splitk_ws_floats", _i64),
-                ("bn_y", _vp), ("bn_py", _i32), ("bn_mean_invstd", _vp), ("bn_gamma", _vp), ("bn_beta", _vp), ("bn_sums", _vp)]
+                ("bn_y", _vp), ("bn_py", _i32), ("bn_mean_invstd", _vp), ("bn_gamma", _vp), ("bn_beta", _vp), ("bn_sums", _vp),
+                ("in_tf", _i32), ("tf_training", _i32), ("tf_y", _vp), ("tf_py", _i32), ("tf_fx", _vp),
+                ("tf_gamma", _vp), ("tf_beta", _vp), ("tf_conv_bias", _vp),
+                ("tf_running_mean", _vp), ("tf_running_var", _vp), ("tf_nbt", _vp), ("tf_mean_invstd", _vp),
+                ("tf_momentum", _f32), ("tf_eps", _f32),
+                ("tf_dgamma", _vp), ("tf_dbeta", _vp), ("tf_dbias", _vp), ("tf_store", _vp), ("tf_ps", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -39,7 +68,7 @@ class WgradDesc(C.Structure):
                 ("src0", _vp), ("C0", _i32), ("P0", _i32),
                 ("src1", _vp), ("C1", _i32), ("P1", _i32),
                 ("dy", _vp), ("Cout", _i32), ("PY", _i32),
-                ("dw", _vp)]
+                ("dw", _vp), ("slab_stride", _i64), ("max_slabs", _i32), ("target_wgs", _i32)]
 
 
 class BnFwdDesc(C.Structure):
@@ -78,6 +107,8 @@ _SIG = {
     "nunet_conv3x3_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "nunet_conv3x3_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "nunet_conv3x3_wgrad_pair": (_i32, [C.POINTER(WgradDesc), C.POINTER(WgradDesc), _vp]),
+    "nunet_conv3x3_wgrad_slabs": (_i32, [C.POINTER(WgradDesc)]),
+    "nunet_wgrad_reduce": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp]),
     "nunet_pack_weights": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "nunet_unpack_wgrad": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "nunet_bn_relu_fwd": (_i32, [C.POINTER(BnFwdDesc), _vp]),

@@ -119,6 +119,81 @@ __device__ __forceinline__ void dec4(const Dec4& d, long long i, int& cg, long l
   }
 }
 
+// ---------------------------------------------------------------------------
+// Order-independent per-channel sums (BatchNorm statistics, BatchNorm-backward sums).
+// Hundreds of workgroups add one partial sum each to the same channel. fp32 atomics would make the
+// result depend on arrival order (run-to-run noise of ~1e-7 relative that the ill-conditioned small
+// cases amplify past the 1e-4 parity bound), so an accumulator is 128-bit FIXED POINT in two int64
+// words, value = hi * 2^-20 + lo * 2^-60: integer atomics commute, the total is bit-identical from
+// run to run and exact to 2^-60 per partial. |partial| is clamped to 2^30 (non-finite -> 2^30).
+// ---------------------------------------------------------------------------
+#define NUNET_FX_WORDS 2
+__device__ __forceinline__ void fx_add(long long* acc, float v) {
+  double s = (v == v) ? (double)v : 1073741824.0;
+  s = fmin(fmax(s, -1073741824.0), 1073741824.0) * 1048576.0;   // exact scaling
+  const double f = floor(s);
+  const long long hi = (long long)f;
+  const long long lo = (long long)((s - f) * 1099511627776.0);  // [0, 2^40)
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)hi);
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc) + 1, (unsigned long long)lo);
+}
+__device__ __forceinline__ double fx_value(long long hi, long long lo) {
+  return (double)hi * (1.0 / 1048576.0) + (double)lo * (1.0 / 1152921504606846976.0);
+}
+// totals of channel c (both values) over the replicas of a [rep][2][C] accumulator array (integer sums: exact, any
+// order). All 2 * NUNET_BN_SUM_REPLICAS 16-byte loads are issued before the first use: ONE memory round trip - this
+// runs in the prologue of every consumer workgroup, where a loop of dependent loads would cost ~1 us per replica.
+typedef __attribute__((ext_vector_type(2))) long long fx2_t;
+__device__ __forceinline__ void fx_totals(const long long* acc, int C, int nrep, int c, double& t0, double& t1) {
+  fx2_t q[NUNET_BN_SUM_REPLICAS][2];
+#pragma unroll
+  for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) {
+    const int rr = r < nrep ? r : 0;            // (re-reads replica 0 instead of branching; masked below)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) q[r][v] = *reinterpret_cast<const fx2_t*>(acc + ((size_t)(rr * 2 + v) * C + c) * NUNET_FX_WORDS);
+  }
+  long long h0 = 0, l0 = 0, h1 = 0, l1 = 0;
+#pragma unroll
+  for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) {
+    const bool on = r < nrep;
+    h0 += on ? q[r][0][0] : 0; l0 += on ? q[r][0][1] : 0;
+    h1 += on ? q[r][1][0] : 0; l1 += on ? q[r][1][1] : 0;
+  }
+  t0 = fx_value(h0, l0); t1 = fx_value(h1, l1);
+}
+
+// BatchNorm2d forward coefficients of channel c (nn.BatchNorm2d at reference finished/archs1.py:19,21).
+// The 3x3 convs store their output WITHOUT the conv bias b (it is absorbed here): the first layers'
+// outputs are bias-dominated (inputs are ~1e-2, reference dataset.py:71), so a 16-bit store of acc+b
+// would lose the signal. With y = acc + b:  train: bn(y) = gamma*(acc - mean(acc))*invstd + beta (the
+// bias cancels and only shifts running_mean);  eval: bn(y) = gamma*(acc - (rm - b))*invstd + beta.
+// `mean` is the value to subtract from the STORED tensor; `mean_full` = E[y]. The batch variance is
+// combined in double from the exact fixed-point totals (E[x^2] - E[x]^2 in fp32 cancels when |mean| >> std).
+struct BnStatArgs {
+  const long long* fx;        // training: [rep][2][C] fixed-point sums of the stored tensor
+  const float* conv_bias;     // or NULL
+  const float* rm; const float* rv;
+  int C, training; float M, eps;
+};
+__device__ __forceinline__ void bn_stat_coeffs(const BnStatArgs& a, int c, float& mean, float& invstd, float& var, float& mean_full) {
+  const float b = a.conv_bias ? a.conv_bias[c] : 0.f;
+  if (a.training) {
+    const int nrep = bn_sum_replicas(a.C);
+    double t1, t2;
+    fx_totals(a.fx, a.C, nrep, c, t1, t2);
+    const double m = t1 / (double)a.M;
+    const double v = t2 / (double)a.M - m * m;
+    mean = (float)m;
+    var = v > 0.0 ? (float)v : 0.f;
+    mean_full = mean + b;
+  } else {
+    mean_full = a.rm[c];
+    mean = mean_full - b;
+    var = a.rv[c];
+  }
+  invstd = 1.0f / sqrtf(var + a.eps);
+}
+
 template <typename T> struct Vec16 {
   // zero-initialised: set() of a 16-bit element read-modify-writes its 32-bit word, and doing that on an
   // indeterminate word is undefined (it miscompiled for fp16 on the odd elements of words 0 and 1)
@@ -145,6 +220,52 @@ template <typename T> struct Vec16 {
     }
   }
 };
+
+// Whole-vector conversion between a 16-byte storage vector and fp32 lanes. With ext_vector types the compiler emits
+// one shift / v_cvt per element on the way in, v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 per PAIR on the way out and packed
+// fp32 math (v_pk_fma_f32) in between - the element-wise get()/set() accessors cost ~3x the VALU instructions, which
+// matters where a transform sits between a global load and an LDS write on a conv's critical path.
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+template <typename T> struct FV { typedef f32x8 type; };
+template <> struct FV<float> { typedef f32x4 type; };
+template <typename T> __device__ __forceinline__ typename FV<T>::type vec_to_f(const Vec16<T>& v) {
+  if constexpr (std::is_same<T, float>::value) return __builtin_bit_cast(f32x4, v.raw);
+  else if constexpr (std::is_same<T, bf16_t>::value) return __builtin_convertvector(__builtin_bit_cast(bf16x8, v.raw), f32x8);
+  else return __builtin_convertvector(__builtin_bit_cast(f16x8, v.raw), f32x8);
+}
+template <typename T> __device__ __forceinline__ Vec16<T> vec_from_f(const typename FV<T>::type& f) {
+  Vec16<T> v;
+  if constexpr (std::is_same<T, float>::value) v.raw = __builtin_bit_cast(u32x4, f);
+  else if constexpr (std::is_same<T, bf16_t>::value) v.raw = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+  else v.raw = __builtin_bit_cast(u32x4, __builtin_convertvector(f, f16x8));
+  return v;
+}
+// fp32 lanes <- EPV consecutive floats of a table (LDS or global), 16-byte aligned
+template <typename T> __device__ __forceinline__ typename FV<T>::type ldf(const float* p) {
+  if constexpr (std::is_same<T, float>::value) return *reinterpret_cast<const f32x4*>(p);
+  else {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  }
+}
+// BatchNorm + ReLU forward / backward-apply on whole vectors; explicit fma so that every kernel that evaluates them
+// (stand-alone BN kernels, the convs' input transforms) rounds identically.
+//   forward : relu(fma(y, sc, sh))
+//   backward: dz = (fma(y, sc, sh) > 0) ? da : 0;  dy = sc * (dz - k1 - xhat * k2) evaluated as fma(sc, dz, -fma(B, y, A))
+//             with B = sc * k2 * invstd, A = sc * k1 - B * mean  (bn_bwd_AB)
+template <typename V> __device__ __forceinline__ V bn_relu_apply(const V& y, const V& sc, const V& sh) {
+  const V z = __builtin_elementwise_fma(y, sc, sh);
+  return __builtin_elementwise_max(z, V(0.f));
+}
+template <typename V> __device__ __forceinline__ V bn_relu_bwd_apply(const V& da, const V& y, const V& sc, const V& sh, const V& A, const V& B) {
+  const V act = __builtin_elementwise_fma(y, sc, sh);
+  const V dz = act > V(0.f) ? da : V(0.f);
+  return __builtin_elementwise_fma(sc, dz, -__builtin_elementwise_fma(B, y, A));
+}
+__device__ __forceinline__ void bn_bwd_AB(float mean, float istd, float sc, float k1, float k2, float& A, float& B) {
+  B = sc * k2 * istd;
+  A = __builtin_fmaf(-B, mean, sc * k1);
+}
 
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
   Vec16<T> v;

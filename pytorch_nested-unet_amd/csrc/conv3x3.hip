@@ -110,7 +110,7 @@ struct ConvP {
   int D0, D1, Q0, Q1;
   int slot_w; unsigned acc0_mask; int acc1;
   unsigned inv_slot_w;   // fastdiv_inv(slot_w): the destination slot of a channel without a division per store unit
-  float* stats;
+  long long* stats;      // fixed-point BatchNorm sums [rep][2][Cout] (common.h fx_add) or NULL
   int N, H, W, Cin, Cout;
   int NI, TH, TW, tilesX, tilesY, tilesG, nCoT, nItems;
   int SH;                // stacked-rows tiling: H + 1 (0 = off), see map_pixel
@@ -118,18 +118,31 @@ struct ConvP {
   unsigned invS, invCoT, invTX, invTY;   // fastdiv_inv of S, nCoT, tilesX, tilesY (item decode)
   int S, nch0, nch;      // K-split: slices, channel chunks of source 0 / total (SK kernels only)
   float* slabs;          // [S][pixels][Cout] fp32 partial sums
-  unsigned* sk_cnt;      // per (tile, Cout-tile) arrival counters (zero before and after every launch); NULL: separate finalize kernel
   long long slab_stride; // pixels * Cout
   // BNR kernels (dgrad of a block's second conv): the BatchNorm+ReLU backward REDUCE pass of the first
   // conv's BN is taken in the epilogue, on the values just stored (dst0 must be dense and assign-only)
   const void* bn_y; int bn_py;            // raw output of the first conv (what that BN normalised)
   const float* bn_mi; const float* bn_gamma; const float* bn_beta;   // saved mean | invstd, affine
-  float* bn_sums;                         // [2][Cout]: sum dz, sum dz * xhat (atomically accumulated)
+  long long* bn_sums;                     // fixed point [rep][2][Cout]: sum dz, sum dz * xhat
+  // LT kernels: the input (source 0, dense, C1 == 0) is TRANSFORMED between the global load and the LDS write
+  //   LT 1: relu(bn(src0))                      - the BatchNorm+ReLU between the two convs of a VGGBlock
+  //   LT 2: BatchNorm+ReLU backward apply        - src0 = dA, tf_y = raw y: dy = sc*(dz - k1 - xhat*k2)
+  // so that neither the activation nor the gradient makes a round trip through HBM on the dependency chain;
+  // the Cout-tile-0 workgroups store the transformed interior pixels for the weight gradient (tf_store).
+  const void* tf_y; int tf_py;
+  const long long* tf_fx;                 // LT 1 (training): sums of the producing conv; LT 2: sum dz, sum dz*xhat
+  const float* tf_gamma; const float* tf_beta; const float* tf_bias;
+  float* tf_rm; float* tf_rv; long long* tf_nbt;
+  float* tf_save;                         // [2][Cin] mean | invstd: written by workgroup 0 (LT 1, training), read (LT 2)
+  int tf_training; float tf_momentum, tf_eps;
+  float* tf_dgamma; float* tf_dbeta; float* tf_dbias;   // LT 2: written by workgroup 0
+  void* tf_store; int tf_ps;
+  float M;                                // N * H * W
 };
 
-template <typename T, int WM_, int WN_, int SM_, int SN_, int KG_ = 1> struct ConvCfg {
-  static constexpr int WM = WM_, WN = WN_, SM = SM_, SN = SN_, KG = KG_;
-  static constexpr int NT = 64 * WM * WN * KG;     // KG wave groups share the tile and split the MFMA steps of every chunk
+template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
+  static constexpr int WM = WM_, WN = WN_, SM = SM_, SN = SN_;
+  static constexpr int NT = 64 * WM * WN;
   static constexpr int BM = 32 * SM * WM;
   static constexpr int BN = 32 * SN * WN;
   static constexpr int EPV = Tr<T>::EPV;
@@ -146,32 +159,35 @@ template <typename T, int WM_, int WN_, int SM_, int SN_, int KG_ = 1> struct Co
   static constexpr int STAGE_ELEMS = (HALO_ELEMS + W_ELEMS) > BM * OS ? (HALO_ELEMS + W_ELEMS) : BM * OS;
 };
 
+// floats of dynamic LDS a launch needs for its per-channel coefficient tables
+static inline int conv_coef_floats(int lt, int cin, bool bnr, int cout) { return (lt == 1 ? 2 : lt == 2 ? 4 : 0) * cin + (bnr ? 4 * cout : 0); }
+
 // Persistent kernel: each workgroup walks (tile, Cout-tile) items with stride gridDim.x.
 // The global loads of the NEXT (item, channel chunk) are issued into registers before the
 // current chunk's MFMA sweep, so HBM latency hides under compute and under the previous
 // tile's epilogue, and co-resident workgroups de-synchronise their load/compute/store phases.
-template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR = false, bool DB = false, int KG = 1, bool FK = false>
-__global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
-  typedef ConvCfg<T, WM, WN, SM, SN, KG> C;
+// Staging is branch-free: C0 and C1 are multiples of the chunk width, so the address of every staging unit is
+// fixed for an item up to the chunk's (uniform) channel offset: pointers are set up once per item, a pixel
+// outside the image points at a page of zeros, and a chunk's staging is 12 plain 16-byte loads.
+template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR, int LT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
+  typedef ConvCfg<T, WM, WN, SM, SN> C;
   typedef Mma<T> M;
   constexpr int PS = C::PS, EPV = C::EPV, BN = C::BN, BM = C::BM, NT = C::NT, KS = C::KS, OS = C::OS;
 
   // one LDS arena: [halo | weights] during the K loop, [BM][OS] output staging in the epilogue
-  __shared__ __attribute__((aligned(16))) T s_buf[(DB ? 2 : 1) * C::STAGE_ELEMS];   // DB: two [halo | weights] stages
+  __shared__ __attribute__((aligned(16))) T s_buf[C::STAGE_ELEMS];
   __shared__ int s_hidx[BM];         // tile-invariant: halo index of output row m
   __shared__ int s_mxy[BM];          // tile-invariant: packed (ni, ly, lx) of row m, -1 unused
   __shared__ int s_hxy[C::HPMAX];    // tile-invariant: packed (ni, hy, hx) of halo pixel, -1 unused
-  __shared__ int s_gpix[BM + 1];     // per item: global pixel of row m, -1 masked; [BM]: K-split "this slice arrived last" flag
+  __shared__ int s_gpix[BM];         // per item: global pixel of row m, -1 masked
   __shared__ float s_red[2 * WM * BN];
-  __shared__ float s_bnc[BNR ? 4 * 512 : 1];   // BNR: [mean | invstd | scale | shift][Cout <= 512], loaded once
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];   // LT tables [2 or 4][Cin], then BNR tables [4][Cout]
   T* const s_halo = s_buf;
   T* const s_w = s_buf + C::HALO_ELEMS;
+  float* const s_bnc = s_coef + (LT == 1 ? 2 : LT == 2 ? 4 : 0) * p.Cin;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
-  // KG > 1: wave group kg owns the MFMA steps st with st % KG == kg of every chunk (twice the waves per SIMD to hide
-  // LDS and MFMA latency when the grid offers one workgroup per CU); group 0 collects the partial sums at the end
-  const int kg = KG > 1 ? wave_all / (WM * WN) : 0;
-  const int wave = KG > 1 ? wave_all % (WM * WN) : wave_all;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
   const int HW2 = p.TW + 2, HH2 = p.TH + 2;
@@ -196,13 +212,6 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
     }
     s_hxy[hp] = code;
   }
-  if constexpr (BNR) {
-    for (int c = tid; c < p.Cout; c += NT) {
-      const float mean = p.bn_mi[c], istd = p.bn_mi[p.Cout + c];
-      const float sc = p.bn_gamma[c] * istd;
-      s_bnc[c] = mean; s_bnc[512 + c] = istd; s_bnc[1024 + c] = sc; s_bnc[1536 + c] = p.bn_beta[c] - mean * sc;
-    }
-  }
   __syncthreads();
 
   int abase[SM];
@@ -213,11 +222,17 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
   for (int tap = 0; tap < 9; ++tap) toff[tap] = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PS;
   const int bbase = ((wn * SN) * 32 + r) * PS + 8 * h;
   int hcode[C::UH];
+  unsigned interior = 0u;            // LT: bit k = staging unit k is a pixel of the tile itself (not its halo ring)
 #pragma unroll
   for (int k = 0; k < C::UH; ++k) {
     const int hp = (tid + k * NT) >> 2;
     hcode[k] = hp < C::HPMAX ? s_hxy[hp] : -1;
+    if (LT != 0 && hcode[k] >= 0) {
+      const int hy = (hcode[k] >> 10) & 1023, hx = hcode[k] & 1023;
+      if (hy >= 1 && hy <= p.TH && hx >= 1 && hx <= p.TW) interior |= 1u << k;
+    }
   }
+  const int seg = tid & 3;           // 16-byte segment of a pixel's chunk row: the same for every unit of a thread (NT % 4 == 0)
 
   struct Item { int co0, n0, y0, x0, ks; };
   auto decode = [&](int item) {
@@ -248,86 +263,73 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
   };
 
   Vec16<T> hreg[C::UH];
+  Vec16<T> yreg[LT == 2 ? C::UH : 1];
   Vec16<T> wreg[C::UW];
-  // units past the valid channels of a chunk are zero-filled, so every chunk runs KS full k-steps
-#ifdef NUNET_ABL
-  bool abl_loaded = false, abl_written = false;   // diagnostic builds (tools/build_ablations.sh) only
-#endif
-  // FK ("full K": C0 and C1 multiples of the chunk width, every staging unit exists): the address of every unit is
-  // fixed for an item up to the chunk's channel offset, which is uniform -> pointers are set up once per item
-  // (a pixel outside the image points at a page of zeros) and a chunk's staging is 12 plain loads: no per-unit
-  // branches, multiplies or zero selects. PMC had counted 828 VALU + 305 SALU instructions per 36 MFMAs per wave
-  // in this loop; with one wave per SIMD that, not the MFMAs or the LDS reads, sets the time of a chunk.
-  const T* hp0[FK ? C::UH : 1]; const T* hp1[FK ? C::UH : 1]; const T* wp[FK ? C::UW : 1];
+  // Staging addresses are 32-bit byte offsets from uniform bases (host-checked to fit): a unit's offset is
+  // pixel * pitch + its 16-byte segment + the chunk's (uniform) channel offset - two VALU per unit and chunk and no
+  // 64-bit pointer per unit held across the MFMA sweep. A pixel outside the image reads pixel 0 and is zeroed on the
+  // way to LDS (write_lds), so a chunk's staging stays 12 plain 16-byte loads without branches.
+  unsigned woff[C::UW];
   auto set_ptrs = [&](const Item& it) {
-    if constexpr (FK) {
-      const T* const zp = reinterpret_cast<const T*>(g_zero_page);
+#pragma unroll
+    for (int k = 0; k < C::UW; ++k) {
+      const int u = tid + k * NT;
+      const int row = u >> 2;
+      const int tap = row / BN, co = row - tap * BN;
+      // (a unit past the last weight row exists when 9*BN*4 is not a multiple of NT; it re-reads row 0 and is never written to LDS)
+      woff[k] = row < 9 * BN ? (unsigned)(((tap * p.Cout + it.co0 + co) * p.Cin + seg * EPV) * (int)sizeof(T)) : (unsigned)(seg * 16);
+    }
+  };
+  auto load_regs = [&](int kb) {
+    const bool s0 = LT != 0 || kb < p.C0;
+    const char* const base = (const char*)(s0 ? p.src0 : p.src1);
+    const unsigned pb = (unsigned)(s0 ? p.P0 : p.P1) * (unsigned)sizeof(T);
+    const unsigned cb = (unsigned)((s0 ? kb : kb - p.C0) * (int)sizeof(T) + seg * 16);
+#pragma unroll
+    for (int k = 0; k < C::UH; ++k) {
+      const unsigned gp = hgp[k] < 0 ? 0u : (unsigned)hgp[k];
+      hreg[k].raw = *reinterpret_cast<const u32x4*>(base + (gp * pb + cb));
+      if constexpr (LT == 2) yreg[k].raw = *reinterpret_cast<const u32x4*>((const char*)p.tf_y + (gp * ((unsigned)p.tf_py * (unsigned)sizeof(T)) + (unsigned)(kb * (int)sizeof(T) + seg * 16)));
+    }
+    const unsigned wb = (unsigned)(kb * (int)sizeof(T));
+#pragma unroll
+    for (int k = 0; k < C::UW; ++k) wreg[k].raw = *reinterpret_cast<const u32x4*>((const char*)p.w + (woff[k] + wb));
+  };
+  // registers -> LDS; LT kernels transform the input on the way. `kb` / `store` belong to the chunk held in the
+  // registers (hgp[] still describes its item: the next item's pixels are mapped only after this write).
+  auto write_lds = [&](int kb, bool store) {
+    if constexpr (LT == 0) {
 #pragma unroll
       for (int k = 0; k < C::UH; ++k) {
-        const int seg = (tid + k * NT) & 3;
-        const bool ok = hgp[k] >= 0;   // (-1 also for units past the halo capacity)
-        hp0[k] = ok ? (const T*)p.src0 + (size_t)hgp[k] * p.P0 + seg * EPV : zp + seg * EPV;
-        hp1[k] = (ok && p.C1 > 0) ? (const T*)p.src1 + (size_t)hgp[k] * p.P1 + seg * EPV : zp + seg * EPV;
-      }
-#pragma unroll
-      for (int k = 0; k < C::UW; ++k) {
         const int u = tid + k * NT;
-        const int row = u >> 2, seg = u & 3;
-        const int tap = row / BN, co = row - tap * BN;
-        // (a unit past the last weight row exists when 9*BN*4 is not a multiple of NT; it is never written to LDS.
-        //  The zero page pointer is biased so that "+ kb" stays inside the page.)
-        wp[k] = row < 9 * BN ? (const T*)p.w + ((size_t)(tap * p.Cout + it.co0 + co)) * p.Cin + seg * EPV : zp;
+        // (the bound check folds away for every k whose whole NT-unit run exists: no branch per unit)
+        if ((k + 1) * NT <= C::HPMAX * 4 || (u >> 2) < C::HPMAX) st16(&s_halo[(u >> 2) * PS + seg * EPV], hgp[k] >= 0 ? hreg[k] : zero16<T>());
+      }
+    } else {
+      typedef typename FV<T>::type V;
+      const int c0 = kb + seg * EPV;
+      const V sc = ldf<T>(&s_coef[c0]), sh = ldf<T>(&s_coef[p.Cin + c0]);
+      V cA, cB;
+      if constexpr (LT == 2) { cA = ldf<T>(&s_coef[2 * p.Cin + c0]); cB = ldf<T>(&s_coef[3 * p.Cin + c0]); }
+#pragma unroll
+      for (int k = 0; k < C::UH; ++k) {
+        const int u = tid + k * NT;
+        if ((k + 1) * NT <= C::HPMAX * 4 || (u >> 2) < C::HPMAX) {
+          const bool ok = hgp[k] >= 0;        // zero padding stays zero: the conv pads the ACTIVATION, not the raw tensor
+          V v;
+          if constexpr (LT == 1) v = bn_relu_apply<V>(vec_to_f<T>(hreg[k]), sc, sh);
+          else v = bn_relu_bwd_apply<V>(vec_to_f<T>(hreg[k]), vec_to_f<T>(yreg[k]), sc, sh, cA, cB);
+          Vec16<T> o = vec_from_f<T>(v);
+          if (!ok) o = zero16<T>();
+          st16(&s_halo[(u >> 2) * PS + seg * EPV], o);
+          if (store && ok && ((interior >> k) & 1u)) st16((T*)p.tf_store + (size_t)hgp[k] * p.tf_ps + c0, o);
+        }
       }
     }
-  };
-  auto load_regs = [&](const Item& it, int kb, int kc) {
-#if defined(NUNET_ABL) && (NUNET_ABL & 1)
-    if (abl_loaded) return;
-    abl_loaded = true;
-#endif
-    if constexpr (FK) {
-      const bool s0 = kb < p.C0;
-      const int ch = s0 ? kb : kb - p.C0;
-#pragma unroll
-      for (int k = 0; k < C::UH; ++k) hreg[k] = ld16((s0 ? hp0[k] : hp1[k]) + ch);
-#pragma unroll
-      for (int k = 0; k < C::UW; ++k) wreg[k] = ld16(wp[k] + kb);
-      return;
-    }
-    const T* src; int ch, pitch;
-    if (kb < p.C0) { src = (const T*)p.src0; ch = kb; pitch = p.P0; }
-    else { src = (const T*)p.src1; ch = kb - p.C0; pitch = p.P1; }
-#pragma unroll
-    for (int k = 0; k < C::UH; ++k) {
-      const int seg = (tid + k * NT) & 3;
-      if (hgp[k] >= 0 && seg * EPV < kc) hreg[k] = ld16(src + (size_t)hgp[k] * pitch + ch + seg * EPV);
-      else hreg[k] = zero16<T>();
-    }
 #pragma unroll
     for (int k = 0; k < C::UW; ++k) {
       const int u = tid + k * NT;
-      const int row = u >> 2, seg = u & 3;
-      if (row < 9 * BN && seg * EPV < kc) {
-        const int tap = row / BN, co = row - tap * BN;
-        wreg[k] = ld16((const T*)p.w + ((size_t)(tap * p.Cout + it.co0 + co)) * p.Cin + kb + seg * EPV);
-      } else wreg[k] = zero16<T>();
-    }
-  };
-  auto write_lds = [&](T* const s_halo, T* const s_w) {
-#if defined(NUNET_ABL) && (NUNET_ABL & 2)
-    if (abl_written) return;
-    abl_written = true;
-#endif
-#pragma unroll
-    for (int k = 0; k < C::UH; ++k) {
-      const int u = tid + k * NT;
-      // (the bound check folds away for every k whose whole NT-unit run exists: no branch per unit)
-      if ((k + 1) * NT <= C::HPMAX * 4 || (u >> 2) < C::HPMAX) st16(&s_halo[(u >> 2) * PS + (u & 3) * EPV], hreg[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < C::UW; ++k) {
-      const int u = tid + k * NT;
-      if ((k + 1) * NT <= 9 * BN * 4 || (u >> 2) < 9 * BN) st16(&s_w[(u >> 2) * PS + (u & 3) * EPV], wreg[k]);
+      if ((k + 1) * NT <= 9 * BN * 4 || (u >> 2) < 9 * BN) st16(&s_w[(u >> 2) * PS + seg * EPV], wreg[k]);
     }
   };
 
@@ -341,323 +343,173 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
 
   // K-split kernels walk channel CHUNKS [c_lo, c_hi) of their slice; plain kernels walk channels
   auto chunk_kb = [&](int c) { return c < p.nch0 ? c * C::KC : p.C0 + (c - p.nch0) * C::KC; };
-  auto chunk_kc = [&](int c) { return min(C::KC, (c < p.nch0 ? p.C0 : p.Cin) - chunk_kb(c)); };
   constexpr int NSTEP = 9 * KS;
-  // steps of wave group G: st = G, G + KG, ...; fragments of the group's next step are read while the current one multiplies
-  auto sweep_g = [&](const T* const s_halo, const T* const s_w, auto gtag) {
-    constexpr int G = decltype(gtag)::value;
-    constexpr int NS = (NSTEP - G + KG - 1) / KG;       // steps of this group
-#if defined(NUNET_ABL) && (NUNET_ABL & 4)
-    if (p.N < 0)
-#endif
-    {
-      typename M::Frag fa[2][SM], fb[2][SN];
-      {
-        constexpr int st0 = G, tap0 = st0 / KS, ks0 = st0 % KS;
+  // fragments of the next step are read while the current one multiplies
+  auto sweep = [&]() {
+    typename M::Frag fa[2][SM], fb[2][SN];
 #pragma unroll
-        for (int a = 0; a < SM; ++a) fa[0][a] = M::load(&s_halo[abase[a] + toff[tap0] + ks0 * 16]);
+    for (int a = 0; a < SM; ++a) fa[0][a] = M::load(&s_halo[abase[a] + toff[0]]);
 #pragma unroll
-        for (int b = 0; b < SN; ++b) fb[0][b] = M::load(&s_w[bbase + (tap0 * BN + b * 32) * PS + ks0 * 16]);
+    for (int b = 0; b < SN; ++b) fb[0][b] = M::load(&s_w[bbase + (b * 32) * PS]);
+#pragma unroll
+    for (int j = 0; j < NSTEP; ++j) {
+      const int cu = j & 1;
+      if (j + 1 < NSTEP) {
+        const int tap = (j + 1) / KS, ks = (j + 1) % KS;
+#pragma unroll
+        for (int a = 0; a < SM; ++a) fa[cu ^ 1][a] = M::load(&s_halo[abase[a] + toff[tap] + ks * 16]);
+#pragma unroll
+        for (int b = 0; b < SN; ++b) fb[cu ^ 1][b] = M::load(&s_w[bbase + (tap * BN + b * 32) * PS + ks * 16]);
       }
 #pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const int cu = j & 1;
-        if (j + 1 < NS) {
-          const int st = (j + 1) * KG + G;
-          const int tap = st / KS, ks = st % KS;
+      for (int a = 0; a < SM; ++a)
 #pragma unroll
-          for (int a = 0; a < SM; ++a) fa[cu ^ 1][a] = M::load(&s_halo[abase[a] + toff[tap] + ks * 16]);
-#pragma unroll
-          for (int b = 0; b < SN; ++b) fb[cu ^ 1][b] = M::load(&s_w[bbase + (tap * BN + b * 32) * PS + ks * 16]);
-        }
-#pragma unroll
-        for (int a = 0; a < SM; ++a)
-#pragma unroll
-          for (int b = 0; b < SN; ++b) M::mma(acc[a][b], fa[cu][a], fb[cu][b]);
-      }
+        for (int b = 0; b < SN; ++b) M::mma(acc[a][b], fa[cu][a], fb[cu][b]);
     }
   };
-  auto sweep = [&](const T* const s_halo, const T* const s_w) {
-    if constexpr (KG == 1) sweep_g(s_halo, s_w, std::integral_constant<int, 0>{});
-    else {
-      if (kg == 0) sweep_g(s_halo, s_w, std::integral_constant<int, 0>{});
-      else sweep_g(s_halo, s_w, std::integral_constant<int, 1>{});
-    }
-  };
-  // KG > 1, end of an item: group 1 hands its partial accumulators to group 0 through LDS (placed behind the
-  // epilogue's output staging so that the two never overlap), then every register->memory step below is group 0's
-  auto collect_groups = [&]() {
-    if constexpr (KG > 1) {
-      __syncthreads();   // every wave is done with the halo / weights of the last chunk
-      float* const s_kg = reinterpret_cast<float*>(s_buf + BM * OS) ;   // [WM*WN waves][SM*SN*16][64 lanes]
-      if (kg == 1) {
+  auto epi_sk = [&](const Item& cur) {
+    // ---- K-split epilogue: this slice's fp32 partial tile goes to its slab (plain stores,
+    // 128-byte runs per half-wave); splitk_finalize_kernel sums the slabs deterministically
+    float* slab = p.slabs + (size_t)cur.ks * p.slab_stride;
 #pragma unroll
-        for (int a = 0; a < SM; ++a)
+    for (int b = 0; b < SN; ++b) {
+      const int co = cur.co0 + (wn * SN + b) * 32 + r;
 #pragma unroll
-          for (int b = 0; b < SN; ++b)
+      for (int a = 0; a < SM; ++a) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s_kg[((wave * SM * SN + a * SN + b) * 16 + i) * 64 + lane] = acc[a][b][i]; acc[a][b][i] = 0.f; }
-      }
-      __syncthreads();
-      if (kg == 0) {
-#pragma unroll
-        for (int a = 0; a < SM; ++a)
-#pragma unroll
-          for (int b = 0; b < SN; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] += s_kg[((wave * SM * SN + a * SN + b) * 16 + i) * 64 + lane];
-      }
-    }
-  };
-  auto epi_sk = [&](const Item& cur, const int item) {
-      // ---- K-split epilogue: this slice's fp32 partial tile goes to its slab (plain stores,
-      // 128-byte runs per half-wave); splitk_finalize_kernel sums the slabs deterministically
-      float* slab = p.slabs + (size_t)cur.ks * p.slab_stride;
-      if (kg == 0) {
-#pragma unroll
-      for (int b = 0; b < SN; ++b) {
-        const int co = cur.co0 + (wn * SN + b) * 32 + r;
-#pragma unroll
-        for (int a = 0; a < SM; ++a) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int gp = s_gpix[(wm * SM + a) * 32 + acc_row(i, h)];
-            if (gp >= 0) slab[(size_t)gp * p.Cout + co] = acc[a][b][i];
-            acc[a][b][i] = 0.f;
-          }
+        for (int i = 0; i < 16; ++i) {
+          const int gp = s_gpix[(wm * SM + a) * 32 + acc_row(i, h)];
+          if (gp >= 0) slab[(size_t)gp * p.Cout + co] = acc[a][b][i];
+          acc[a][b][i] = 0.f;
         }
       }
-      }
-      if constexpr (SK) {
-        if (p.sk_cnt) {
-          // ---- last arriver finalizes the tile (no separate finalize launch): every slice publishes its slab
-          // (device-scope fence), then counts itself in; the slice that completes the count sums the S slabs in
-          // fixed order (deterministic), adds the bias, converts, routes, and takes the BatchNorm statistics
-          __threadfence();
-          __syncthreads();
-          if (tid == 0) {
-            const int tix = item / p.S;
-            const unsigned old = atomicAdd(&p.sk_cnt[tix], 1u);
-            const bool last = old == (unsigned)(p.S - 1);
-            if (last) p.sk_cnt[tix] = 0u;             // all S arrivals are in: leave the counter clean for the next launch
-            s_gpix[BM] = last ? 1 : 0;
-          }
-          __syncthreads();
-          if (s_gpix[BM]) {
-            __threadfence();
-            constexpr int SEGS = BN / EPV;
-            float q1[EPV], q2[EPV];
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) { q1[e] = 0.f; q2[e] = 0.f; }
-#pragma unroll
-            for (int k = 0; k < C::UO; ++k) {
-              const int u = tid + k * NT;
-              const int m = u / SEGS, seg = u - m * SEGS;
-              const int gp = m < BM ? s_gpix[m] : -1;
-              if (gp >= 0) {
-                const int co = cur.co0 + seg * EPV;
-                float x[EPV];
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) x[e] = 0.f;
-                for (int sl = 0; sl < p.S; ++sl) {
-                  const f32x4* w4 = reinterpret_cast<const f32x4*>(p.slabs + (size_t)sl * p.slab_stride + (size_t)gp * p.Cout + co);
-#pragma unroll
-                  for (int v4 = 0; v4 < EPV / 4; ++v4) {
-                    const f32x4 t4 = w4[v4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[v4 * 4 + e] += t4[e];
-                  }
-                }
-                T* q; bool accum;
-                if (co < p.D0) { q = (T*)p.dst0 + (size_t)gp * p.Q0 + co; accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u; }
-                else { q = (T*)p.dst1 + (size_t)gp * p.Q1 + (co - p.D0); accum = p.acc1 != 0; }
-                const Vec16<T> o = accum ? ld16(q) : zero16<T>();
-                Vec16<T> v;
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                  const float bb = p.bias ? p.bias[co + e] : 0.f;
-                  float y = x[e] + bb;
-                  if (accum) y += o.get(e);
-                  v.set(e, y);
-                  const float d = to_f32(from_f32<T>(y)) - bb;
-                  q1[e] += d; q2[e] += d * d;
-                }
-                st16(q, v);
-              }
-            }
-            if (p.stats) {
-#pragma unroll
-              for (int off = SEGS; off < 64; off <<= 1) {
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) { q1[e] += __shfl_xor(q1[e], off); q2[e] += __shfl_xor(q2[e], off); }
-              }
-              float* s_fin = reinterpret_cast<float*>(s_buf);     // [waves][2][BN]; the staging arena is idle here
-              if (lane < SEGS) {
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                  s_fin[(wave * 2 + 0) * BN + lane * EPV + e] = q1[e];
-                  s_fin[(wave * 2 + 1) * BN + lane * EPV + e] = q2[e];
-                }
-              }
-              __syncthreads();
-              float* const stp = p.stats + (size_t)(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout;
-              for (int t = tid; t < 2 * BN; t += NT) {
-                const int vsel = t / BN, c = t - vsel * BN;
-                float sum = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < WM * WN; ++wv) sum += s_fin[(wv * 2 + vsel) * BN + c];
-                atomicAdd(&stp[vsel * p.Cout + cur.co0 + c], sum);
-              }
-            }
-          }
-        }
-      }
+    }
   };
   auto epi_plain = [&](const Item& cur, T* const s_out) {
-      // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
-      // BNR: the y1 vectors of this thread's store units are requested NOW, so their latency hides under
-      // the accumulator -> LDS transposition below instead of being exposed once per unit in the store loop
-      Vec16<T> byv[BNR ? C::UO : 1];
-      if constexpr (BNR) {
-        constexpr int SEGS0 = BN / EPV;
-#pragma unroll
-        for (int k = 0; k < C::UO; ++k) {
-          const int u = tid + k * NT;
-          const int m = u / SEGS0, seg = u - m * SEGS0;
-          const int gp = m < BM ? s_gpix[m] : -1;
-#if defined(NUNET_ABL) && (NUNET_ABL & 16)
-          if (gp >= 0 && p.N < 0) byv[k] = ld16((const T*)p.bn_y + (size_t)gp * p.bn_py + cur.co0 + seg * EPV);
-#else
-          if (gp >= 0) byv[k] = ld16((const T*)p.bn_y + (size_t)gp * p.bn_py + cur.co0 + seg * EPV);
-#endif
-        }
-      }
-      __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
-      if (kg == 0) {
-#pragma unroll
-      for (int b = 0; b < SN; ++b) {
-        const int cl = (wn * SN + b) * 32 + r;  // channel within the tile
-        const float bias = p.bias ? p.bias[cur.co0 + cl] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < SM; ++a) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int m = (wm * SM + a) * 32 + acc_row(i, h);
-            const T tv = from_f32<T>(acc[a][b][i] + bias);
-            s_out[m * OS + cl] = tv;
-            if (p.stats && s_gpix[m] >= 0) {
-              const float d = to_f32(tv) - bias;
-              s1 += d; s2 += d * d;
-            }
-            acc[a][b][i] = 0.f;
-          }
-        }
-        if (p.stats) {
-          s1 += __shfl_xor(s1, 32);
-          s2 += __shfl_xor(s2, 32);
-          if (h == 0) { s_red[(wm * BN + cl) * 2 + 0] = s1; s_red[(wm * BN + cl) * 2 + 1] = s2; }
-        }
-      }
-      }
-      __syncthreads();
-      constexpr int SEGS = BN / EPV;
-      // BNR: every unit of a thread has the same channel segment (NT % SEGS == 0), so the BN-backward
-      // partial sums of its 8 channels live in registers across the store loop
-      float bmean[BNR ? EPV : 1], bistd[BNR ? EPV : 1], bsc[BNR ? EPV : 1], bsh[BNR ? EPV : 1], r1[BNR ? EPV : 1], r2[BNR ? EPV : 1];
-      if constexpr (BNR) {
-        const int c0 = cur.co0 + (tid % SEGS) * EPV;
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-          bmean[e] = s_bnc[c0 + e]; bistd[e] = s_bnc[512 + c0 + e]; bsc[e] = s_bnc[1024 + c0 + e]; bsh[e] = s_bnc[1536 + c0 + e];
-          r1[e] = 0.f; r2[e] = 0.f;
-        }
-      }
+    // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
+    // BNR: the y1 vectors of this thread's store units are requested NOW, so their latency hides under
+    // the accumulator -> LDS transposition below instead of being exposed once per unit in the store loop
+    Vec16<T> byv[BNR ? C::UO : 1];
+    if constexpr (BNR) {
+      constexpr int SEGS0 = BN / EPV;
 #pragma unroll
       for (int k = 0; k < C::UO; ++k) {
         const int u = tid + k * NT;
-        const int m = u / SEGS, seg = u - m * SEGS;
-        if (m < BM) {
-          const int gp = s_gpix[m];
-#if defined(NUNET_ABL) && (NUNET_ABL & 8)
-          if (gp >= 0 && p.N < 0) {
-#else
-          if (gp >= 0) {
-#endif
-            const int co = cur.co0 + seg * EPV;
-            T* q; bool accum;
-            if (co < p.D0) {
-              q = (T*)p.dst0 + (size_t)gp * p.Q0 + co;
-              accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u;
-            } else {
-              q = (T*)p.dst1 + (size_t)gp * p.Q1 + (co - p.D0);
-              accum = p.acc1 != 0;
-            }
-            Vec16<T> v = ld16(&s_out[m * OS + seg * EPV]);
-            if (accum) {
-              const Vec16<T> o = ld16(q);
-#pragma unroll
-              for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + o.get(e));
-            }
-            st16(q, v);
-#if defined(NUNET_ABL) && (NUNET_ABL & 32)
-            if constexpr (BNR) if (p.N < 0) {
-#else
-            if constexpr (BNR) {
-#endif
-              const Vec16<T> yv = byv[k];
-#pragma unroll
-              for (int e = 0; e < EPV; ++e) {
-                const float yy = yv.get(e);
-                const float dz = (yy * bsc[e] + bsh[e]) > 0.f ? v.get(e) : 0.f;   // the stored (rounded) gradient
-                r1[e] += dz;
-                r2[e] += dz * ((yy - bmean[e]) * bistd[e]);
-              }
-            }
-          }
-        }
+        const int m = u / SEGS0, sg = u - m * SEGS0;
+        const int gp = m < BM ? s_gpix[m] : -1;
+        if (gp >= 0) byv[k] = ld16((const T*)p.bn_y + (size_t)gp * p.bn_py + cur.co0 + sg * EPV);
       }
-      if constexpr (BNR) {
-        // lanes that share a channel segment (lane % SEGS) are summed with xor-shuffles, the four waves
-        // through a small LDS table, then one atomic per channel and sum
-#if !(defined(NUNET_ABL) && (NUNET_ABL & 64))
+    }
+    __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
 #pragma unroll
-        for (int off = SEGS; off < 64; off <<= 1) {
+    for (int b = 0; b < SN; ++b) {
+      const int cl = (wn * SN + b) * 32 + r;  // channel within the tile
+      const float bias = p.bias ? p.bias[cur.co0 + cl] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int e = 0; e < EPV; ++e) { r1[e] += __shfl_xor(r1[e], off); r2[e] += __shfl_xor(r2[e], off); }
-        }
-#endif
-        __syncthreads();                                   // s_out reads of the store loop are done
-        float* s_bn = reinterpret_cast<float*>(s_buf);     // [waves][2][BN]
-        if (lane < SEGS) {
+      for (int a = 0; a < SM; ++a) {
 #pragma unroll
-          for (int e = 0; e < EPV; ++e) {
-            s_bn[(wave * 2 + 0) * BN + lane * EPV + e] = r1[e];
-            s_bn[(wave * 2 + 1) * BN + lane * EPV + e] = r2[e];
+        for (int i = 0; i < 16; ++i) {
+          const int m = (wm * SM + a) * 32 + acc_row(i, h);
+          const T tv = from_f32<T>(acc[a][b][i] + bias);
+          s_out[m * OS + cl] = tv;
+          if (p.stats && s_gpix[m] >= 0) {
+            const float d = to_f32(tv) - bias;
+            s1 += d; s2 += d * d;
           }
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * BN; t += NT) {
-          const int vsel = t / BN, c = t - vsel * BN;
-          float sum = 0.f;
-#pragma unroll
-          for (int wv = 0; wv < WM * WN; ++wv) sum += s_bn[(wv * 2 + vsel) * BN + c];
-#if defined(NUNET_ABL) && (NUNET_ABL & 128)
-          if (p.N < 0)
-#endif
-          atomicAdd(&p.bn_sums[((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c], sum);
+          acc[a][b][i] = 0.f;
         }
       }
       if (p.stats) {
-        for (int c = tid; c < BN; c += NT) {
-          float s1 = 0.f, s2 = 0.f;
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (h == 0) { s_red[(wm * BN + cl) * 2 + 0] = s1; s_red[(wm * BN + cl) * 2 + 1] = s2; }
+      }
+    }
+    __syncthreads();
+    constexpr int SEGS = BN / EPV;
+    // BNR: every unit of a thread has the same channel segment (NT % SEGS == 0), so the BN-backward
+    // partial sums of its 8 channels live in registers across the store loop
+    float bmean[BNR ? EPV : 1], bistd[BNR ? EPV : 1], bsc[BNR ? EPV : 1], bsh[BNR ? EPV : 1], r1[BNR ? EPV : 1], r2[BNR ? EPV : 1];
+    if constexpr (BNR) {
+      const int c0 = cur.co0 + (tid % SEGS) * EPV;
 #pragma unroll
-          for (int k = 0; k < WM; ++k) { s1 += s_red[(k * BN + c) * 2]; s2 += s_red[(k * BN + c) * 2 + 1]; }
-          float* const st = p.stats + (size_t)(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout;   // replica of this workgroup
-          atomicAdd(&st[cur.co0 + c], s1);
-          atomicAdd(&st[p.Cout + cur.co0 + c], s2);
+      for (int e = 0; e < EPV; ++e) {
+        bmean[e] = s_bnc[c0 + e]; bistd[e] = s_bnc[p.Cout + c0 + e]; bsc[e] = s_bnc[2 * p.Cout + c0 + e]; bsh[e] = s_bnc[3 * p.Cout + c0 + e];
+        r1[e] = 0.f; r2[e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < C::UO; ++k) {
+      const int u = tid + k * NT;
+      const int m = u / SEGS, sg = u - m * SEGS;
+      if (m < BM) {
+        const int gp = s_gpix[m];
+        if (gp >= 0) {
+          const int co = cur.co0 + sg * EPV;
+          T* q; bool accum;
+          if (co < p.D0) {
+            q = (T*)p.dst0 + (size_t)gp * p.Q0 + co;
+            accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u;
+          } else {
+            q = (T*)p.dst1 + (size_t)gp * p.Q1 + (co - p.D0);
+            accum = p.acc1 != 0;
+          }
+          Vec16<T> v = ld16(&s_out[m * OS + sg * EPV]);
+          if (accum) {
+            const Vec16<T> o = ld16(q);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + o.get(e));
+          }
+          st16(q, v);
+          if constexpr (BNR) {
+            const Vec16<T> yv = byv[k];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+              const float yy = yv.get(e);
+              const float dz = __builtin_fmaf(yy, bsc[e], bsh[e]) > 0.f ? v.get(e) : 0.f;   // the stored (rounded) gradient
+              r1[e] += dz;
+              r2[e] += dz * ((yy - bmean[e]) * bistd[e]);
+            }
+          }
         }
       }
+    }
+    if constexpr (BNR) {
+      // lanes that share a channel segment (lane % SEGS) are summed with xor-shuffles, the four waves
+      // through a small LDS table (fixed order), then one fixed-point add per channel and sum
+#pragma unroll
+      for (int off = SEGS; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { r1[e] += __shfl_xor(r1[e], off); r2[e] += __shfl_xor(r2[e], off); }
+      }
+      __syncthreads();                                   // s_out reads of the store loop are done
+      float* s_bn = reinterpret_cast<float*>(s_buf);     // [waves][2][BN]
+      if (lane < SEGS) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          s_bn[(wave * 2 + 0) * BN + lane * EPV + e] = r1[e];
+          s_bn[(wave * 2 + 1) * BN + lane * EPV + e] = r2[e];
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < 2 * BN; t += NT) {
+        const int vsel = t / BN, c = t - vsel * BN;
+        float sum = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < WM * WN; ++wv) sum += s_bn[(wv * 2 + vsel) * BN + c];
+        fx_add(p.bn_sums + ((size_t)((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum);
+      }
+    }
+    if (p.stats) {
+      for (int t = tid; t < 2 * BN; t += NT) {
+        const int vsel = t / BN, c = t - vsel * BN;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) sum += s_red[(k * BN + c) * 2 + vsel];
+        fx_add(p.stats + ((size_t)((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum);
+      }
+    }
   };
   int item = blockIdx.x;
   if (item >= p.nItems) return;
@@ -665,15 +517,61 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
   set_hgp(cur);
   set_ptrs(cur);
   int cc = 0, c_hi = 0;
-  int kb = 0, kc = 0;
-  if constexpr (SK) { cc = cur.ks * p.nch / p.S; c_hi = (cur.ks + 1) * p.nch / p.S; kb = chunk_kb(cc); kc = chunk_kc(cc); }
-  else { kc = min(C::KC, (kb < p.C0 ? p.C0 : p.Cin) - kb); }
-  load_regs(cur, kb, kc);
+  int kb = 0;
+  if constexpr (SK) { cc = cur.ks * p.nch / p.S; c_hi = (cur.ks + 1) * p.nch / p.S; kb = chunk_kb(cc); }
+  load_regs(kb);
   bool first_chunk = true;
+  // per-channel coefficient tables, AFTER the first tile's loads were issued (the two global-memory latencies overlap);
+  // the barrier at the top of the loop orders them before the first write_lds / epilogue
+  if constexpr (BNR) {
+    for (int c = tid; c < p.Cout; c += NT) {
+      const float mean = p.bn_mi[c], istd = p.bn_mi[p.Cout + c];
+      const float sc = p.bn_gamma[c] * istd;
+      s_bnc[c] = mean; s_bnc[p.Cout + c] = istd; s_bnc[2 * p.Cout + c] = sc; s_bnc[3 * p.Cout + c] = __builtin_fmaf(-mean, sc, p.bn_beta[c]);
+    }
+  }
+  if constexpr (LT == 1) {
+    // BatchNorm coefficients of the INPUT channels, from the producing conv's fixed-point sums (every workgroup
+    // derives the same values; workgroup 0 also owns the running-statistics update and the saved mean / invstd)
+    BnStatArgs a; a.fx = p.tf_fx; a.conv_bias = p.tf_bias; a.rm = p.tf_rm; a.rv = p.tf_rv; a.C = p.Cin; a.training = p.tf_training; a.M = p.M; a.eps = p.tf_eps;
+    for (int c = tid; c < p.Cin; c += NT) {
+      float mean, invstd, var, mf;
+      bn_stat_coeffs(a, c, mean, invstd, var, mf);
+      const float sc = p.tf_gamma[c] * invstd;
+      s_coef[c] = sc; s_coef[p.Cin + c] = __builtin_fmaf(-mean, sc, p.tf_beta[c]);
+      if (blockIdx.x == 0 && p.tf_training) {
+        if (p.tf_save) { p.tf_save[c] = mean; p.tf_save[p.Cin + c] = invstd; }
+        if (p.tf_rm) {
+          const float unb = p.M > 1.f ? var * (p.M / (p.M - 1.f)) : var;
+          p.tf_rm[c] = (1.f - p.tf_momentum) * p.tf_rm[c] + p.tf_momentum * mf;
+          p.tf_rv[c] = (1.f - p.tf_momentum) * p.tf_rv[c] + p.tf_momentum * unb;
+        }
+      }
+    }
+    if (blockIdx.x == 0 && p.tf_training && tid == 0 && p.tf_nbt) *p.tf_nbt += 1;
+  }
+  if constexpr (LT == 2) {
+    const int nrep = bn_sum_replicas(p.Cin);
+    for (int c = tid; c < p.Cin; c += NT) {
+      const float mean = p.tf_save[c], istd = p.tf_save[p.Cin + c];
+      const float sc = p.tf_gamma[c] * istd;
+      double t1, t2;
+      fx_totals(p.tf_fx, p.Cin, nrep, c, t1, t2);
+      float A, B;
+      bn_bwd_AB(mean, istd, sc, (float)(t1 / (double)p.M), (float)(t2 / (double)p.M), A, B);
+      s_coef[c] = sc; s_coef[p.Cin + c] = __builtin_fmaf(-mean, sc, p.tf_beta[c]); s_coef[2 * p.Cin + c] = A; s_coef[3 * p.Cin + c] = B;
+      if (blockIdx.x == 0) {
+        // d beta = sum dz, d gamma = sum dz * xhat; the conv bias in front of a BatchNorm has gradient sum(dy) == 0
+        if (p.tf_dbeta) p.tf_dbeta[c] = (float)t1;
+        if (p.tf_dgamma) p.tf_dgamma[c] = (float)t2;
+        if (p.tf_dbias) p.tf_dbias[c] = 0.f;
+      }
+    }
+  }
 
   while (true) {
     __syncthreads();  // previous chunk's fragment reads / previous item's epilogue reads are done
-    write_lds(s_halo, s_w);
+    write_lds(kb, LT != 0 && p.tf_store != nullptr && cur.co0 == 0);
     if (first_chunk) {
       for (int m = tid; m < BM; m += NT) {
         const int code = s_mxy[m];
@@ -687,7 +585,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
     }
     __syncthreads();
     // prefetch the next (item, chunk) into registers
-    int nkb = kb + kc, nkc = 0, nitem = item, ncc = cc + 1, nc_hi = c_hi;
+    int nkb = kb + C::KC, nitem = item, ncc = cc + 1, nc_hi = c_hi;
     Item nxt = cur;
     bool have_next = true;
     bool last_chunk;
@@ -701,62 +599,56 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv3x3_kernel(ConvP p) {
       } else have_next = false;
     }
     if (have_next) {
-      if constexpr (SK) { nkb = chunk_kb(ncc); nkc = chunk_kc(ncc); }
-      else nkc = min(C::KC, (nkb < p.C0 ? p.C0 : p.Cin) - nkb);
-      load_regs(nxt, nkb, nkc);
+      if constexpr (SK) nkb = chunk_kb(ncc);
+      load_regs(nkb);
     }
-    sweep(s_halo, s_w);
+    sweep();
     first_chunk = false;
-    if (SK && last_chunk) {
-      collect_groups();
-      epi_sk(cur, item);
-      if (!have_next) break;
-      cur = nxt; item = nitem; first_chunk = true;
-    } else if (last_chunk) {
-      collect_groups();
-      epi_plain(cur, s_buf);
+    if (last_chunk) {
+      if constexpr (SK) epi_sk(cur); else epi_plain(cur, s_buf);
       if (!have_next) break;
       cur = nxt; item = nitem; first_chunk = true;
     }
-    kb = nkb; kc = nkc; cc = ncc; c_hi = nc_hi;
+    kb = nkb; cc = ncc; c_hi = nc_hi;
   }
 }
 
 // Finishes a K-split convolution: sum of the S fp32 slabs (fixed order: deterministic) -> (+bias)
 // -> T, routed to the two destinations with the per-slot accumulate mask, BatchNorm partial sums.
+// The block size is a multiple of the channel groups G, so every element a thread visits has the same
+// channel group: statistics are summed in registers, meet in LDS in a fixed order, one fixed-point add per channel.
 struct SplitFinP {
   const float* slabs; long long slab_stride; int S; const float* bias;
   void* dst0; void* dst1; int D0, D1, Q0, Q1; int slot_w; unsigned acc0_mask; int acc1; unsigned inv_slot_w;
-  float* stats; long long npix; int Cout;
-  const void* bn_y; int bn_py; const float* bn_mi; const float* bn_gamma; const float* bn_beta; float* bn_sums;   // see ConvP
+  long long* stats; long long npix; int Cout;
+  const void* bn_y; int bn_py; const float* bn_mi; const float* bn_gamma; const float* bn_beta; long long* bn_sums;   // see ConvP
 };
-template <typename T, bool BNR = false>
+template <typename T, bool BNR>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
   constexpr int EPV = Tr<T>::EPV;
-  __shared__ float s_st[2 * 1024];
-  __shared__ float s_bn[BNR ? 6 * 1024 : 1];   // [mean | invstd | scale | shift | sum dz | sum dz*xhat][Cout]
-  const int G = p.Cout / EPV;
-  if (p.stats) for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x) s_st[c] = 0.f;
-  if constexpr (BNR) {
-    for (int c = threadIdx.x; c < p.Cout; c += blockDim.x) {
+  constexpr int NV = BNR ? 4 : 2;
+  __shared__ float s_part[256 * NV * EPV];
+  const int G = p.Cout / EPV;                 // blockDim.x % G == 0
+  const int cg = threadIdx.x % G, co = cg * EPV;
+  const int ppb = blockDim.x / G, pl = threadIdx.x / G;
+  float q1[EPV], q2[EPV], r1[BNR ? EPV : 1], r2[BNR ? EPV : 1];
+  float bmean[BNR ? EPV : 1], bistd[BNR ? EPV : 1], bsc[BNR ? EPV : 1], bsh[BNR ? EPV : 1], bias[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    q1[e] = 0.f; q2[e] = 0.f;
+    bias[e] = p.bias ? p.bias[co + e] : 0.f;
+    if constexpr (BNR) {
+      const int c = co + e;
       const float mean = p.bn_mi[c], istd = p.bn_mi[p.Cout + c];
       const float sc = p.bn_gamma[c] * istd;
-      s_bn[c] = mean; s_bn[p.Cout + c] = istd; s_bn[2 * p.Cout + c] = sc; s_bn[3 * p.Cout + c] = p.bn_beta[c] - mean * sc;
-      s_bn[4 * p.Cout + c] = 0.f; s_bn[5 * p.Cout + c] = 0.f;
+      bmean[e] = mean; bistd[e] = istd; bsc[e] = sc; bsh[e] = __builtin_fmaf(-mean, sc, p.bn_beta[c]);
+      r1[e] = 0.f; r2[e] = 0.f;
     }
   }
-  __syncthreads();
-  const long long total = p.npix * G;
-  // when the block size is a multiple of G every element a thread visits has the same channel group: the statistics are
-  // summed in registers and meet in LDS once per thread (per-element LDS atomics on G*EPV addresses were most of this kernel)
-  const bool fixed_cg = (blockDim.x % G) == 0;
-  float q1[EPV], q2[EPV];
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) { q1[e] = 0.f; q2[e] = 0.f; }
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % G);
-    const long long pix = i / G;
-    const int co = cg * EPV;
+  T* q; bool accum; long long qstride;
+  if (co < p.D0) { q = (T*)p.dst0 + co; qstride = p.Q0; accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u; }
+  else { q = (T*)p.dst1 + (co - p.D0); qstride = p.Q1; accum = p.acc1 != 0; }
+  for (long long pix = (long long)blockIdx.x * ppb + pl; pix < p.npix; pix += (long long)gridDim.x * ppb) {
     float x[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) x[e] = 0.f;
@@ -769,50 +661,46 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(SplitFinP p) {
         for (int e = 0; e < 4; ++e) x[v4 * 4 + e] += q4[e];
       }
     }
-    T* q; bool accum;
-    if (co < p.D0) { q = (T*)p.dst0 + pix * p.Q0 + co; accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u; }
-    else { q = (T*)p.dst1 + pix * p.Q1 + (co - p.D0); accum = p.acc1 != 0; }
-    const Vec16<T> o = accum ? ld16(q) : zero16<T>();
+    T* qq = q + pix * qstride;
+    const Vec16<T> o = accum ? ld16(qq) : zero16<T>();
     Vec16<T> v;
+    float stored[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      const float b = p.bias ? p.bias[co + e] : 0.f;
-      float y = x[e] + b;
+      float y = x[e] + bias[e];
       if (accum) y += o.get(e);
       v.set(e, y);
-      if (p.stats) {
-        const float d = to_f32(from_f32<T>(y)) - b;   // the stored (rounded) value; not v.get(e) right after v.set(e)
-        if (fixed_cg) { q1[e] += d; q2[e] += d * d; }
-        else { atomicAdd(&s_st[co + e], d); atomicAdd(&s_st[p.Cout + co + e], d * d); }
-      }
+      stored[e] = to_f32(from_f32<T>(y));   // the stored (rounded) value; not v.get(e) right after v.set(e)
+      const float d = stored[e] - bias[e];
+      q1[e] += d; q2[e] += d * d;
     }
-    st16(q, v);
+    st16(qq, v);
     if constexpr (BNR) {
       const Vec16<T> yv = ld16((const T*)p.bn_y + pix * p.bn_py + co);
 #pragma unroll
       for (int e = 0; e < EPV; ++e) {
-        const int c = co + e;
         const float yy = yv.get(e);
-        const float dz = (yy * s_bn[2 * p.Cout + c] + s_bn[3 * p.Cout + c]) > 0.f ? v.get(e) : 0.f;
-        atomicAdd(&s_bn[4 * p.Cout + c], dz);
-        atomicAdd(&s_bn[5 * p.Cout + c], dz * ((yy - s_bn[c]) * s_bn[p.Cout + c]));
+        const float dz = __builtin_fmaf(yy, bsc[e], bsh[e]) > 0.f ? stored[e] : 0.f;
+        r1[e] += dz; r2[e] += dz * ((yy - bmean[e]) * bistd[e]);
       }
     }
   }
-  if constexpr (BNR) {
-    __syncthreads();
-    for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x)
-      atomicAdd(&p.bn_sums[(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout + c], s_bn[4 * p.Cout + c]);
-  }
-  if (p.stats) {
-    if (fixed_cg) {
-      const int co = (threadIdx.x % G) * EPV;
+  if (!p.stats && !BNR) return;
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) { atomicAdd(&s_st[co + e], q1[e]); atomicAdd(&s_st[p.Cout + co + e], q2[e]); }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < 2 * p.Cout; c += blockDim.x)
-      atomicAdd(&p.stats[(size_t)(blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 * p.Cout + c], s_st[c]);
+  for (int e = 0; e < EPV; ++e) {
+    s_part[(threadIdx.x * NV + 0) * EPV + e] = q1[e];
+    s_part[(threadIdx.x * NV + 1) * EPV + e] = q2[e];
+    if constexpr (BNR) { s_part[(threadIdx.x * NV + 2) * EPV + e] = r1[e]; s_part[(threadIdx.x * NV + 3) * EPV + e] = r2[e]; }
+  }
+  __syncthreads();
+  const int rep = blockIdx.x & (bn_sum_replicas(p.Cout) - 1);
+  for (int t = threadIdx.x; t < NV * p.Cout; t += blockDim.x) {
+    const int v = t / p.Cout, c = t - v * p.Cout;
+    const int g = c / EPV, e = c - g * EPV;
+    float sum = 0.f;
+    for (int qd = 0; qd < ppb; ++qd) sum += s_part[((qd * G + g) * NV + v) * EPV + e];
+    if (v < 2) { if (p.stats) fx_add(p.stats + ((size_t)(rep * 2 + v) * p.Cout + c) * NUNET_FX_WORDS, sum); }
+    else fx_add(p.bn_sums + ((size_t)(rep * 2 + (v - 2)) * p.Cout + c) * NUNET_FX_WORDS, sum);
   }
 }
 
@@ -840,9 +728,7 @@ TileGeom nunet_choose_tile(int N, int H, int W, int BM, int HPMAX) {
   }
   // stacked-rows candidates (map_pixel): TH virtual rows x full width over N * (H + 1) virtual rows;
   // taken only when they beat the best regular tiling by a clear margin (they waste the separator rows)
-  static int stacked = -1;
-  if (stacked < 0) { const char* e = getenv("NUNET_STACKED_TILES"); stacked = e ? atoi(e) : 1; }
-  if (stacked && W <= BM && (long)N * (H + 1) < (1 << 20) && H + 1 <= 4096) {
+  if (W <= BM && (long)N * (H + 1) < (1 << 20) && H + 1 <= 4096) {
     const double best_util = (double)N * H * W / ((double)best.tilesX * best.tilesY * best.tilesG * BM);
     const int VH = N * (H + 1);
     double su = 0.0; int sth = 0;
@@ -857,6 +743,14 @@ TileGeom nunet_choose_tile(int N, int H, int W, int BM, int HPMAX) {
   return best;
 }
 
+template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR>
+static void launch_conv_lt(int lt, unsigned grid, size_t dyn, hipStream_t st, const ConvP& p) {
+  typedef ConvCfg<T, WM, WN, SM, SN> C;
+  if (lt == 1) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 1>), dim3(grid), dim3(C::NT), dyn, st, p);
+  else if (lt == 2) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 2>), dim3(grid), dim3(C::NT), dyn, st, p);
+  else hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 0>), dim3(grid), dim3(C::NT), dyn, st, p);
+}
+
 template <typename T, int WM, int WN, int SM, int SN>
 static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
@@ -865,10 +759,16 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.w = d->wpack; p.bias = d->bias;
   p.dst0 = d->dst0; p.dst1 = d->dst1; p.D0 = d->D0; p.D1 = d->D1; p.Q0 = d->Q0; p.Q1 = d->Q1;
   p.slot_w = d->acc_slot_w; p.acc0_mask = d->acc0_mask; p.acc1 = d->acc1; p.inv_slot_w = fastdiv_inv(d->acc_slot_w);
-  p.stats = d->stats;
+  p.stats = (long long*)d->stats;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1; p.Cout = d->D0 + d->D1;
+  p.M = (float)d->N * d->H * d->W;
   const bool bnr = d->bn_y != nullptr;
-  p.bn_y = d->bn_y; p.bn_py = d->bn_py; p.bn_mi = d->bn_mean_invstd; p.bn_gamma = d->bn_gamma; p.bn_beta = d->bn_beta; p.bn_sums = d->bn_sums;
+  const int lt = d->in_tf;
+  p.bn_y = d->bn_y; p.bn_py = d->bn_py; p.bn_mi = d->bn_mean_invstd; p.bn_gamma = d->bn_gamma; p.bn_beta = d->bn_beta; p.bn_sums = (long long*)d->bn_sums;
+  p.tf_y = d->tf_y; p.tf_py = d->tf_py; p.tf_fx = (const long long*)d->tf_fx; p.tf_gamma = d->tf_gamma; p.tf_beta = d->tf_beta; p.tf_bias = d->tf_conv_bias;
+  p.tf_rm = d->tf_running_mean; p.tf_rv = d->tf_running_var; p.tf_nbt = (long long*)d->tf_nbt; p.tf_save = d->tf_mean_invstd;
+  p.tf_training = d->tf_training; p.tf_momentum = d->tf_momentum; p.tf_eps = d->tf_eps;
+  p.tf_dgamma = d->tf_dgamma; p.tf_dbeta = d->tf_dbeta; p.tf_dbias = d->tf_dbias; p.tf_store = d->tf_store; p.tf_ps = d->tf_ps;
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
   p.SHinv = g.SH ? (unsigned)(((1ull << 32) + g.SH - 1) / g.SH) : 0u;
@@ -876,110 +776,68 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   long items = (long)p.nCoT * g.tilesX * g.tilesY * g.tilesG;
   // K-split for the grid-starved deep levels: slices of the channel-chunk loop become extra items, each
   // writes an fp32 partial slab; splitk_finalize_kernel sums them (fixed order, deterministic)
-  p.S = 1; p.slabs = nullptr; p.slab_stride = 0; p.sk_cnt = nullptr;
-  p.nch0 = ceil_div(p.C0, C::KC);
-  p.nch = p.nch0 + (p.C1 > 0 ? ceil_div(p.C1, C::KC) : 0);
-  static int sk_max_items = -1;
-  if (sk_max_items < 0) { const char* e = getenv("NUNET_SK_MAXITEMS"); sk_max_items = e ? atoi(e) : 100; }
-  // the first NUNET_SPLITK_COUNTER_FLOATS floats of the workspace are the arrival counters of the in-kernel
-  // finalize (zero before the first use, left zero by every launch); the slabs follow
-  static int sk_inkernel = -1;
-  if (sk_inkernel < 0) { const char* e = getenv("NUNET_SK_INKERNEL"); sk_inkernel = e ? atoi(e) : 0;   /* measured: the device-scope fences (L2 write-back + invalidate on every workgroup) cost 470 us per step: off */ }
-  if (d->splitk_ws && d->splitk_ws_floats > NUNET_SPLITK_COUNTER_FLOATS && items <= sk_max_items && p.nch >= 8 && p.Cout <= 1024) {
+  p.S = 1; p.slabs = nullptr; p.slab_stride = 0;
+  p.nch0 = p.C0 / C::KC;
+  p.nch = p.nch0 + p.C1 / C::KC;
+  if (d->splitk_ws && items <= 100 && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
     int S = (int)((320 + items - 1) / items);
     if (S > p.nch / 2) S = p.nch / 2;
     const long long need = (long long)S * d->N * d->H * d->W * p.Cout;
-    if (S > 1 && need <= d->splitk_ws_floats - NUNET_SPLITK_COUNTER_FLOATS) {
-      p.S = S; p.slabs = d->splitk_ws + NUNET_SPLITK_COUNTER_FLOATS; p.slab_stride = (long long)d->N * d->H * d->W * p.Cout;
-      if (sk_inkernel && !bnr && items <= NUNET_SPLITK_COUNTER_FLOATS) p.sk_cnt = reinterpret_cast<unsigned*>(d->splitk_ws);
+    if (S > 1 && need <= d->splitk_ws_floats) {
+      p.S = S; p.slabs = d->splitk_ws; p.slab_stride = (long long)d->N * d->H * d->W * p.Cout;
       items *= S;
     }
   }
   p.nItems = (int)items;
   p.invS = fastdiv_inv(p.S); p.invCoT = fastdiv_inv(p.nCoT); p.invTX = fastdiv_inv(p.tilesX); p.invTY = fastdiv_inv(p.tilesY);
-  // KG = 2 (8 waves share the tile, each group takes every other MFMA step of a chunk): when the grid offers at most
-  // one workgroup per CU anyway, twice the waves per SIMD hide LDS/MFMA latency. 16-bit types only (LDS budget of the
-  // cross-group hand-over). NUNET_CONV_KG: 0 off, 1 auto (items <= NUNET_CONV_KG_MAXITEMS), 2 always.
-  static int kg_mode = -1, kg_max_items = 0;
-  if (kg_mode < 0) {
-    const char* e = getenv("NUNET_CONV_KG"); kg_mode = e ? atoi(e) : 0;
-    e = getenv("NUNET_CONV_KG_MAXITEMS"); kg_max_items = e ? atoi(e) : 300;
-  }
-  const bool use_kg = sizeof(T) == 2 && !bnr && !p.sk_cnt && (kg_mode == 2 || (kg_mode == 1 && items <= kg_max_items));
   // persistent grid: resident workgroups only, item counts balanced across them
-  const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN + (d->bn_y ? 8192 : 0);
+  const size_t dyn = sizeof(float) * (size_t)conv_coef_floats(lt, p.Cin, bnr && p.S == 1, p.Cout);
+  const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN + dyn;
   long per_cu = (long)(160 * 1024 / lds_bytes);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2048 / C::NT) per_cu = 2048 / C::NT;
-  if (use_kg) per_cu = 1;   // 8 waves x > 128 registers: one workgroup per CU
   const long resident = 256 * per_cu;
   const long rounds = (items + resident - 1) / resident;
   const long grid = (items + rounds - 1) / rounds;
   const double px = (double)d->N * d->H * d->W;
   const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
   ProfScope ps(C::BN == 32 ? PC_CONV_M256N32 : PC_CONV_M128N64,  /* BN 64 configs share a class */ 2.0 * 9 * acin * p.Cout * px,
-               (px * (acin + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
-  // FK: branch-free staging when every chunk is full (see the kernel). NUNET_CONV_FK=0 turns it off.
-  static int fk_mode = -1;
-  if (fk_mode < 0) { const char* e = getenv("NUNET_CONV_FK"); fk_mode = e ? atoi(e) : 1; }
-  const bool use_fk = fk_mode && !bnr && !use_kg && d->C0 % C::KC == 0 && d->C1 % C::KC == 0 && (size_t)p.Cin * sizeof(T) <= 8192;
-  if (use_fk) {
-    if (p.S > 1) {
-      hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true, false, false, 1, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
-    } else {
-      hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, false, false, 1, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
-      return nunet_check_launch("conv3x3 (full-K staging)");
-    }
-  }
+               (px * (acin * (lt == 2 ? 2 : 1) + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
   if (p.S > 1) {
-    if constexpr (sizeof(T) == 2) {
-      if (use_kg) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true, false, false, 2>), dim3((unsigned)grid), dim3(2 * C::NT), 0, st, p);
-    }
-    if (!use_kg && !use_fk) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
-    if (p.sk_cnt) return nunet_check_launch("conv3x3 (K-split, in-kernel finalize)");
+    launch_conv_lt<T, WM, WN, SM, SN, true, false>(lt, (unsigned)grid, dyn, st, p);
     SplitFinP f;
     f.slabs = p.slabs; f.slab_stride = p.slab_stride; f.S = p.S; f.bias = p.bias;
     f.dst0 = p.dst0; f.dst1 = p.dst1; f.D0 = p.D0; f.D1 = p.D1; f.Q0 = p.Q0; f.Q1 = p.Q1;
     f.slot_w = p.slot_w; f.acc0_mask = p.acc0_mask; f.acc1 = p.acc1; f.inv_slot_w = p.inv_slot_w; f.stats = p.stats;
     f.npix = (long long)d->N * d->H * d->W; f.Cout = p.Cout;
     f.bn_y = p.bn_y; f.bn_py = p.bn_py; f.bn_mi = p.bn_mi; f.bn_gamma = p.bn_gamma; f.bn_beta = p.bn_beta; f.bn_sums = p.bn_sums;
-    long long fg = (f.npix * (p.Cout / C::EPV) + 255) / 256;
+    const int G = p.Cout / C::EPV;
+    const int blk = G * (256 / G);
+    long long fg = (f.npix + (blk / G) - 1) / (blk / G);
     if (fg > 1024) fg = 1024;
-    if (bnr) hipLaunchKernelGGL((splitk_finalize_kernel<T, true>), dim3((unsigned)fg), dim3(256), 0, st, f);
-    else hipLaunchKernelGGL((splitk_finalize_kernel<T, false>), dim3((unsigned)fg), dim3(256), 0, st, f);
+    if (bnr) hipLaunchKernelGGL((splitk_finalize_kernel<T, true>), dim3((unsigned)fg), dim3(blk), 0, st, f);
+    else hipLaunchKernelGGL((splitk_finalize_kernel<T, false>), dim3((unsigned)fg), dim3(blk), 0, st, f);
     return nunet_check_launch("conv3x3 (K-split)");
   }
-  if constexpr (sizeof(T) == 2) {
-    if (use_kg) {
-      hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, false, false, 2>), dim3((unsigned)grid), dim3(2 * C::NT), 0, st, p);
-      return nunet_check_launch("conv3x3 (2 wave groups)");
-    }
-  }
-  if (bnr) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
-  else hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, false, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  if (bnr) launch_conv_lt<T, WM, WN, SM, SN, false, true>(lt, (unsigned)grid, dyn, st, p);
+  else launch_conv_lt<T, WM, WN, SM, SN, false, false>(lt, (unsigned)grid, dyn, st, p);
   return nunet_check_launch("conv3x3");
 }
 
 template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream_t st) {
   const int cout = d->D0 + d->D1;
-  static int big = -1;   // measured: the 256x64 tile drops to 1 wave/SIMD (296 registers) and loses; off by default
-  if (big < 0) { const char* e = getenv("NUNET_CONV_BIG"); big = e ? atoi(e) : 0; }
-  const long px = (long)d->N * d->H * d->W;
-  if (cout % 64 == 0) {
-    // deep pyramid levels are weight-streaming bound: every M-tile re-reads the layer's whole weight
-    // slab, so few pixels -> the largest tile (256 px x 64 co, 64x64 per wave: 1.0 LDS reads per MFMA),
-    // parallelism restored by the K-split
-    if (big && px <= big * 10000L && d->splitk_ws) return launch_conv_cfg<T, 4, 1, 2, 2>(d, st);   // BM 256, BN 64
-    return launch_conv_cfg<T, 2, 2, 2, 1>(d, st);                                       // BM 128, BN 64
-  }
-  return launch_conv_cfg<T, 4, 1, 2, 1>(d, st);                                         // BM 256, BN 32
+  // Cout multiple of 64: 128 pixels x 64 channels per workgroup (2 x 2 waves of 64 x 32); otherwise 256 x 32
+  if (cout % 64 == 0) return launch_conv_cfg<T, 2, 2, 2, 1>(d, st);
+  return launch_conv_cfg<T, 4, 1, 2, 1>(d, st);
 }
 
 extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {
   NUNET_REQUIRE(d && d->src0 && d->wpack && d->dst0, "conv3x3: null pointer");
   const int cin = d->C0 + d->C1, cout = d->D0 + d->D1;
+  NUNET_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "conv3x3: bad dtype %d", d->dtype);
+  const int kc = 64 / dtype_size(d->dtype);
   NUNET_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "conv3x3: bad extent %dx%dx%d", d->N, d->H, d->W);
-  NUNET_REQUIRE(d->C0 > 0 && d->C0 % 16 == 0 && d->C1 % 16 == 0, "conv3x3: C0=%d C1=%d must be multiples of 16", d->C0, d->C1);
+  NUNET_REQUIRE(d->C0 > 0 && d->C0 % kc == 0 && d->C1 % kc == 0, "conv3x3: C0=%d C1=%d must be multiples of %d (64-byte channel chunks)", d->C0, d->C1, kc);
   NUNET_REQUIRE(d->C1 == 0 || d->src1, "conv3x3: src1 null with C1=%d", d->C1);
   NUNET_REQUIRE(cout % 32 == 0 && d->D0 % 32 == 0 && d->D1 % 32 == 0, "conv3x3: D0=%d D1=%d must be multiples of 32", d->D0, d->D1);
   NUNET_REQUIRE(d->D1 == 0 || d->dst1, "conv3x3: dst1 null with D1=%d", d->D1);
@@ -987,11 +845,29 @@ extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {
   const int epv = 16 / dtype_size(d->dtype);
   NUNET_REQUIRE(d->P0 % epv == 0 && (d->C1 == 0 || d->P1 % epv == 0), "conv3x3: source pitch must keep 16-byte alignment");
   NUNET_REQUIRE(d->acc_slot_w == 0 || d->acc_slot_w % 32 == 0, "conv3x3: acc_slot_w %d", d->acc_slot_w);
-  NUNET_REQUIRE((long)d->N * d->H * d->W < (1L << 30) && cin <= 4096, "conv3x3: problem too large for 32-bit pixel indices");
+  {
+    // staging uses 32-bit byte offsets from the tensor bases
+    const unsigned long long px = (unsigned long long)d->N * d->H * d->W, es = dtype_size(d->dtype);
+    const unsigned long long lim = 1ull << 32;
+    NUNET_REQUIRE(px < (1ull << 30) && px * d->P0 * es < lim && (d->C1 == 0 || px * d->P1 * es < lim) && 9ull * cout * cin * es < lim &&
+                  (d->in_tf != 2 || px * d->tf_py * es < lim), "conv3x3: problem too large (every input tensor must span < 4 GB)");
+  }
   if (d->bn_y) {
     NUNET_REQUIRE(d->bn_mean_invstd && d->bn_gamma && d->bn_beta && d->bn_sums, "conv3x3: fused BN-backward reduce needs mean/invstd, gamma, beta and sums");
-    NUNET_REQUIRE(d->D1 == 0 && d->Q0 == d->D0 && d->acc0_mask == 0 && d->bn_py % (16 / dtype_size(d->dtype)) == 0 && cout <= 512,
+    NUNET_REQUIRE(d->D1 == 0 && d->Q0 == d->D0 && d->acc0_mask == 0 && d->bn_py % epv == 0 && cout <= 512,
                   "conv3x3: fused BN-backward reduce needs one dense, assign-only destination");
+  }
+  NUNET_REQUIRE(d->in_tf >= 0 && d->in_tf <= 2, "conv3x3: in_tf %d", d->in_tf);
+  if (d->in_tf) {
+    NUNET_REQUIRE(d->C1 == 0 && cin <= 1024, "conv3x3: an input transform needs a single source (C1 == 0) of at most 1024 channels");
+    NUNET_REQUIRE(d->tf_gamma && d->tf_beta, "conv3x3: input transform needs gamma and beta");
+    NUNET_REQUIRE(!d->tf_store || d->tf_ps % epv == 0, "conv3x3: tf_store pitch alignment");
+    if (d->in_tf == 1) {
+      if (d->tf_training) NUNET_REQUIRE(d->tf_fx, "conv3x3: BN input transform in training mode needs the producing conv's sums");
+      else NUNET_REQUIRE(d->tf_running_mean && d->tf_running_var, "conv3x3: BN input transform in eval mode needs running statistics");
+    } else {
+      NUNET_REQUIRE(d->tf_y && d->tf_fx && d->tf_mean_invstd && d->tf_py % epv == 0, "conv3x3: BN-backward input transform needs y, sums and saved mean/invstd");
+    }
   }
   return NUNET_DISPATCH(d->dtype, launch_conv, d, (hipStream_t)s);
 }
@@ -999,18 +875,15 @@ extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {
 // ---------------------------------------------------------------------------
 // wgrad kernel
 //
-// Work item = (32 Cout) x (32 Cin) x 9 taps of dW, over a slice of the pixel tiles.
-// All 4 waves of a workgroup accumulate the SAME output block over different pixels of
-// each 128-pixel tile (intra-workgroup split of the contraction), so no wave idles for
-// narrow layers; partials are summed through LDS once, then added atomically to the fp32
-// gradient. Tiles are double-buffered in LDS; the next tile's global loads are in flight
-// (in registers) while the current one multiplies.
+// Work item = (32 Cout) x (32 Cin) x 9 taps of dW, over a slice of the pixel tiles (K-split). Every
+// slice writes its partial block to its own fp32 slab with plain stores; the slabs are summed in a
+// fixed order afterwards (nunet_wgrad_reduce), so the gradient is bit-identical from run to run.
 // ---------------------------------------------------------------------------
 struct WgP {
   const void* src0; const void* src1;
   int C0, C1, P0, P1;
   const void* dy; int Cout, PY;
-  float* dw;
+  float* dw; long long slab_stride;   // slab s of the K-split at dw + s * slab_stride, [9][Cout][Cin] each
   int N, H, W, Cin;
   int NI, TH, TW, tilesX, tilesY, tilesG;
   int nCoT, nCiT, ksplit, nMT;
@@ -1194,8 +1067,11 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
     mt = nmt;
   }
 
-  // one atomic per output element of this wave's three taps
+  // this slice's partial gradient block goes to ITS slab with plain stores (no atomics: 256 workgroups adding
+  // 9216 floats each to the same 36.8 KB block serialise memory-side, and the sum would depend on arrival order);
+  // nunet_wgrad_reduce / the plan's reduce launch sums the slabs in fixed order
   const int ci = ci0 + r;
+  float* const slab = p.dw + (size_t)split * p.slab_stride;
   if (ci < p.Cin) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -1203,13 +1079,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = co0 + acc_row(i, h);
-#if defined(NUNET_ABL) && (NUNET_ABL & 256)
-        if (co < p.Cout) p.dw[((size_t)tap * p.Cout + co) * p.Cin + ci] = acc[t][i];    // timing experiment: no atomics
-#elif defined(NUNET_ABL) && (NUNET_ABL & 512)
-        if (co < p.Cout) atomicAdd(&p.dw[(size_t)(split & 7) * 9 * p.Cout * p.Cin + ((size_t)tap * p.Cout + co) * p.Cin + ci], acc[t][i]);   // timing experiment: 8 replicas (dw must be 8x)
-#else
-        if (co < p.Cout) atomicAdd(&p.dw[((size_t)tap * p.Cout + co) * p.Cin + ci], acc[t][i]);
-#endif
+        if (co < p.Cout) slab[((size_t)tap * p.Cout + co) * p.Cin + ci] = acc[t][i];
       }
     }
   }
@@ -1227,11 +1097,30 @@ __global__ __launch_bounds__(192) void wgrad_pair_kernel(WgP pa, WgP pb, int na)
   else wgrad_body<T, ST>(pb, blockIdx.x - na);
 }
 
-template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p, int target_override = 0) {
+// K-split slices of a weight-gradient problem: enough (32 x 32 x 9) work items for `target` workgroups, at most one
+// slice per 128-pixel tile and at most `max_slabs` (the caller's slab capacity). Pure function of the descriptor.
+static int wgrad_slices(const nunet_wgrad_desc* d, const TileGeom& g) {
+  const int otiles = ceil_div(d->Cout, 32) * ceil_div(d->C0 + d->C1, 32);
+  const int nMT = g.tilesX * g.tilesY * g.tilesG;
+  int ks = ceil_div(d->target_wgs > 0 ? d->target_wgs : 256, otiles);
+  if (ks > nMT) ks = nMT;
+  if (d->max_slabs > 0 && ks > d->max_slabs) ks = d->max_slabs;
+  if (ks < 1) ks = 1;
+  return ks;
+}
+extern "C" int32_t nunet_conv3x3_wgrad_slabs(const nunet_wgrad_desc* d) {
+  if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->C0 <= 0) return 0;
+  const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, 128, 192);
+  return wgrad_slices(d, g);
+}
+
+template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p) {
   typedef WgCfg<T> C;
+  static_assert(C::BM == 128 && C::HPMAX == 192, "nunet_conv3x3_wgrad_slabs assumes this tile");
   p.src0 = d->src0; p.src1 = d->src1; p.C0 = d->C0; p.C1 = d->C1; p.P0 = d->P0; p.P1 = d->P1;
   p.dy = d->dy; p.Cout = d->Cout; p.PY = d->PY; p.dw = d->dw;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1;
+  p.slab_stride = d->slab_stride > 0 ? d->slab_stride : 9LL * p.Cout * p.Cin;
   const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
   p.SHinv = g.SH ? (unsigned)(((1ull << 32) + g.SH - 1) / g.SH) : 0u;
@@ -1239,14 +1128,8 @@ template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p,
   p.nCoT = ceil_div(p.Cout, 32);
   p.nCiT = ceil_div(p.Cin, 32);
   p.nMT = g.tilesX * g.tilesY * g.tilesG;
-  const int otiles = p.nCoT * p.nCiT;
-  static int wg_target = 0;
-  if (!wg_target) { const char* e = getenv("NUNET_WG_TARGET"); wg_target = e ? atoi(e) : 256; }
-  int ks = ceil_div(target_override > 0 ? target_override : wg_target, otiles);
-  if (ks > p.nMT) ks = p.nMT;
-  if (ks < 1) ks = 1;
-  p.ksplit = ks;
-  return (long)otiles * ks;
+  p.ksplit = wgrad_slices(d, g);
+  return (long)p.nCoT * p.nCiT * p.ksplit;
 }
 template <typename T> static void wgrad_prof(const nunet_wgrad_desc* d, const WgP& p, double& flops, double& bytes) {
   const double px = (double)d->N * d->H * d->W;
@@ -1270,12 +1153,7 @@ struct WgPairArgs { const nunet_wgrad_desc* a; const nunet_wgrad_desc* b; };
 template <typename T> static int launch_wgrad_pair(const WgPairArgs* w, hipStream_t st) {
   typedef WgCfg<T> C;
   WgP pa, pb;
-  // in a pair the chip is filled by both problems together: the smaller one (fewer input channels) can take
-  // fewer K-split slices, i.e. fewer same-address atomics (NUNET_WG_TARGET_SMALL, default 128: +0.7 % on the step)
-  static int small_target = -1;
-  if (small_target < 0) { const char* e = getenv("NUNET_WG_TARGET_SMALL"); small_target = e ? atoi(e) : 128; }
-  const int cin_a = w->a->C0 + w->a->C1, cin_b = w->b->C0 + w->b->C1;
-  const long ga = wgrad_setup<T>(w->a, pa, cin_a < cin_b ? small_target : 0), gb = wgrad_setup<T>(w->b, pb, cin_b < cin_a ? small_target : 0);
+  const long ga = wgrad_setup<T>(w->a, pa), gb = wgrad_setup<T>(w->b, pb);
   double fa, ba, fb, bb; wgrad_prof<T>(w->a, pa, fa, ba);
   { const int keep = g_prof_alg_cin; g_prof_alg_cin = 0; wgrad_prof<T>(w->b, pb, fb, bb); g_prof_alg_cin = keep; }
   ProfScope ps(pa.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fa + fb, ba + bb, st);
@@ -1297,6 +1175,8 @@ static int wgrad_check(const nunet_wgrad_desc* d) {
   const int epv = 16 / dtype_size(d->dtype);
   NUNET_REQUIRE(d->P0 % epv == 0 && (d->C1 == 0 || d->P1 % epv == 0) && d->PY % epv == 0, "wgrad: pitch alignment");
   NUNET_REQUIRE((long)d->N * d->H * d->W < (1L << 30), "wgrad: too many pixels");
+  NUNET_REQUIRE(d->slab_stride == 0 || d->slab_stride >= 9LL * d->Cout * (d->C0 + d->C1), "wgrad: slab_stride smaller than one slab");
+  NUNET_REQUIRE(d->max_slabs >= 0 && d->target_wgs >= 0, "wgrad: max_slabs / target_wgs");
   return NUNET_OK;
 }
 extern "C" int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s) {
@@ -1312,4 +1192,22 @@ extern "C" int nunet_conv3x3_wgrad_pair(const nunet_wgrad_desc* a, const nunet_w
   NUNET_REQUIRE(a->dtype == b->dtype, "wgrad_pair: the two problems must share the dtype");
   WgPairArgs w{a, b};
   return NUNET_DISPATCH(a->dtype, launch_wgrad_pair, &w, (hipStream_t)s);
+}
+
+// Sum of the K-split slabs of a weight gradient (fixed order: bit-reproducible): out[i] (+)= sum_s slabs[s * stride + i].
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, long long stride, int ns, float* __restrict__ out, long long n4, int accumulate) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ns; ++s) { const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride + i * 4); a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3]; }
+    f32x4* q = reinterpret_cast<f32x4*>(out + i * 4);
+    if (accumulate) { const f32x4 o = *q; a[0] += o[0]; a[1] += o[1]; a[2] += o[2]; a[3] += o[3]; }
+    *q = a;
+  }
+}
+extern "C" int nunet_wgrad_reduce(const float* slabs, int64_t slab_stride, int32_t nslabs, int64_t n, float* out, int32_t accumulate, nunet_stream_t s) {
+  NUNET_REQUIRE(slabs && out && nslabs >= 1 && n > 0 && n % 4 == 0 && slab_stride % 4 == 0, "wgrad_reduce: bad args (n and slab_stride multiples of 4)");
+  NUNET_REQUIRE(((uintptr_t)slabs & 15) == 0 && ((uintptr_t)out & 15) == 0, "wgrad_reduce: 16-byte alignment");
+  long long g = (n / 4 + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, slabs, (long long)slab_stride, nslabs, out, (long long)(n / 4), accumulate);
+  return nunet_check_launch("wgrad_reduce");
 }

@@ -132,47 +132,23 @@ extern "C" int nunet_preprocess_u8(const uint8_t* u8_nhwc, int32_t N, int32_t H,
 // ---------------------------------------------------------------------------
 struct BnFwdP {
   const void* y; int PY;
-  const float* conv_bias; const float* stats; const float* gamma; const float* beta;
+  const float* conv_bias; const long long* stats; const float* gamma; const float* beta;
   float* rm; float* rv; int64_t* nbt; float* save;
   int training; float momentum, eps;
   void* a; int PA; void* pooled; int PP;
   int N, H, W, C;
 };
 
-// The 3x3 convs store their output WITHOUT the conv bias (it is absorbed here):
-// the first layers' outputs are bias-dominated (inputs are ~1e-2, reference
-// dataset.py:71), so a 16-bit store of acc+bias would lose the signal. With
-// y = acc + b:  train: bn(y) = gamma*(acc - mean(acc))*invstd + beta (bias cancels;
-// it only shifts running_mean);  eval: bn(y) = gamma*(acc - (rm - b))*invstd + beta.
-// `mean` is the value to subtract from the STORED tensor; `mean_full` = E[y].
+// (the conv bias is absorbed here, see bn_stat_coeffs in common.h)
 __device__ __forceinline__ void bn_channel_coeffs(const BnFwdP& p, int c, float M, float& mean, float& invstd, float& var, float& mean_full) {
-  const float b = p.conv_bias ? p.conv_bias[c] : 0.f;
-  if (p.training) {
-    float t1 = 0.f, t2 = 0.f;   // the producing conv adds to bn_sum_replicas(C) replicas (include/nunet.h)
-    const int nrep = bn_sum_replicas(p.C);
-    float q1[NUNET_BN_SUM_REPLICAS], q2[NUNET_BN_SUM_REPLICAS];
-#pragma unroll
-    for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) {   // all loads in flight at once
-      q1[r] = r < nrep ? p.stats[(r * 2 + 0) * p.C + c] : 0.f;
-      q2[r] = r < nrep ? p.stats[(r * 2 + 1) * p.C + c] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) { t1 += q1[r]; t2 += q2[r]; }
-    mean = t1 / M;
-    var = fmaxf(t2 / M - mean * mean, 0.f);
-    mean_full = mean + b;
-  } else {
-    mean_full = p.rm[c];
-    mean = mean_full - b;
-    var = p.rv[c];
-  }
-  invstd = 1.0f / sqrtf(var + p.eps);
+  BnStatArgs a; a.fx = p.stats; a.conv_bias = p.conv_bias; a.rm = p.rm; a.rv = p.rv; a.C = p.C; a.training = p.training; a.M = M; a.eps = p.eps;
+  bn_stat_coeffs(a, c, mean, invstd, var, mean_full);
 }
 
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   constexpr int EPV = Tr<T>::EPV;
-  __shared__ float s_sc[2048], s_sh[2048];
+  __shared__ __attribute__((aligned(16))) float s_sc[2048], s_sh[2048];
   const int G = p.C / EPV;  // channel groups; 256 % G == 0
   const int cg = threadIdx.x % G;
   const float M = (float)p.N * p.H * p.W;
@@ -222,7 +198,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
     bn_channel_coeffs(p, c, M, mean, invstd, var, mf);
     const float sc = p.gamma[c] * invstd;
     s_sc[c] = sc;
-    s_sh[c] = p.beta[c] - mean * sc;
+    s_sh[c] = __builtin_fmaf(-mean, sc, p.beta[c]);
     if (blockIdx.x == 0 && p.training) {
       p.save[c] = mean;
       p.save[p.C + c] = invstd;
@@ -235,9 +211,8 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   }
   if (blockIdx.x == 0 && p.training && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
   __syncthreads();
-  float sc[EPV], sh[EPV];
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) { sc[e] = s_sc[cg * EPV + e]; sh[e] = s_sh[cg * EPV + e]; }
+  typedef typename FV<T>::type V;
+  const V sc = ldf<T>(&s_sc[cg * EPV]), sh = ldf<T>(&s_sh[cg * EPV]);
   const int ppb = blockDim.x / G;  // pixels (or quads) per block iteration
   const int pl = threadIdx.x / G;
   if constexpr (!POOL) {
@@ -246,12 +221,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t pix = pix0 + u * stride;
-        if (pix < npix) {
-          Vec16<T> o;
-#pragma unroll
-          for (int e = 0; e < EPV; ++e) o.set(e, fmaxf(v[u].get(e) * sc[e] + sh[e], 0.f));
-          st16((T*)p.a + pix * p.PA + cg * EPV, o);
-        }
+        if (pix < npix) st16((T*)p.a + pix * p.PA + cg * EPV, vec_from_f<T>(bn_relu_apply<V>(vec_to_f<T>(v[u]), sc, sh)));
       }
       pix0 += U * stride;
       if (pix0 < npix) load_batch(pix0);
@@ -261,28 +231,18 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
     int64_t q = q0;
     while (q < nq) {
       const int64_t p00 = p00_cur;
-      float mx[EPV];
+      // the running maximum is taken over the ROUNDED activations (what a later pool would see): converting the stored
+      // vector back is exact, and max is order-independent
+      V mx;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int64_t pix = p00 + (k >> 1) * p.W + (k & 1);
-        const Vec16<T> v = vq[k];
-        Vec16<T> o;
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-          const float a = fmaxf(v.get(e) * sc[e] + sh[e], 0.f);
-          o.set(e, a);
-          // rounded value, as a later pool would see it (rounded explicitly: reading it back with o.get(e)
-          // right after o.set(e) miscompiled for fp16 on the odd lanes of the packed words)
-          float ar = to_f32(from_f32<T>(a));
-          asm volatile("" : "+v"(ar));   // keep the running maximum in fp32 registers (see above)
-          mx[e] = (k == 0) ? ar : fmaxf(mx[e], ar);
-        }
+        const Vec16<T> o = vec_from_f<T>(bn_relu_apply<V>(vec_to_f<T>(vq[k]), sc, sh));
+        const V ar = vec_to_f<T>(o);
+        mx = (k == 0) ? ar : __builtin_elementwise_max(mx, ar);
         st16((T*)p.a + pix * p.PA + cg * EPV, o);
       }
-      Vec16<T> po;
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) po.set(e, mx[e]);
-      st16((T*)p.pooled + q * p.PP + cg * EPV, po);
+      st16((T*)p.pooled + q * p.PP + cg * EPV, vec_from_f<T>(mx));
       q += (int64_t)gridDim.x * ppb;
       if (q < nq) qload(q);
     }
@@ -291,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
 
 template <typename T> static int launch_bn_fwd(const nunet_bn_fwd_desc* d, hipStream_t st) {
   BnFwdP p;
-  p.y = d->y; p.PY = d->PY; p.conv_bias = d->conv_bias; p.stats = d->stats; p.gamma = d->gamma; p.beta = d->beta;
+  p.y = d->y; p.PY = d->PY; p.conv_bias = d->conv_bias; p.stats = (const long long*)d->stats; p.gamma = d->gamma; p.beta = d->beta;
   p.rm = d->running_mean; p.rv = d->running_var; p.nbt = d->num_batches_tracked; p.save = d->save_mean_invstd;
   p.training = d->training; p.momentum = d->momentum; p.eps = d->eps;
   p.a = d->a; p.PA = d->PA; p.pooled = d->pooled; p.PP = d->PP;
@@ -326,7 +286,7 @@ extern "C" int nunet_bn_relu_fwd(const nunet_bn_fwd_desc* d, nunet_stream_t s) {
 struct BnBwdP {
   const void* da; int PDA; const void* y; int PY;
   const float* mi; const float* gamma; const float* beta;
-  float* sums; float* dgamma; float* dbeta; float* dbias;
+  long long* sums; float* dgamma; float* dbeta; float* dbias;
   void* dy; int PDY;
   int N, H, W, C;
 };
@@ -334,9 +294,9 @@ struct BnBwdP {
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
   constexpr int EPV = Tr<T>::EPV;
-  constexpr int NV = APPLY ? 1 : 2;                 // partial sums per channel
-  __shared__ float s_co[6 * 2048 / 4];              // coefficient tables, C <= 512: [6][C]
-  __shared__ float s_part[256 * NV * EPV];          // per-thread partials for the block reduction
+  constexpr int NV = 2;                             // partial sums per channel (reduce pass)
+  __shared__ __attribute__((aligned(16))) float s_co[6 * 2048 / 4];   // coefficient tables, C <= 512: [6][C]
+  __shared__ float s_part[APPLY ? 1 : 256 * NV * EPV];   // per-thread partials for the block reduction
   const int G = p.C / EPV;
   const int cg = threadIdx.x % G;
   const int ppb = blockDim.x / G, pl = threadIdx.x / G;
@@ -363,80 +323,73 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float mean = p.mi[c], istd = p.mi[C + c];
     const float sc = p.gamma[c] * istd;
-    s_co[c] = mean; s_co[C + c] = istd; s_co[2 * C + c] = sc; s_co[3 * C + c] = p.beta[c] - mean * sc;
+    s_co[c] = mean; s_co[C + c] = istd; s_co[2 * C + c] = sc; s_co[3 * C + c] = __builtin_fmaf(-mean, sc, p.beta[c]);
     if constexpr (APPLY) {
-      float t1 = 0.f, t2 = 0.f;
       const int nrep = bn_sum_replicas(C);
-      float q1[NUNET_BN_SUM_REPLICAS], q2[NUNET_BN_SUM_REPLICAS];
-#pragma unroll
-      for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) {   // all loads in flight at once
-        q1[r] = r < nrep ? p.sums[(r * 2 + 0) * C + c] : 0.f;
-        q2[r] = r < nrep ? p.sums[(r * 2 + 1) * C + c] : 0.f;
+      double t1, t2;
+      fx_totals(p.sums, C, nrep, c, t1, t2);
+      float A, B;
+      bn_bwd_AB(mean, istd, sc, (float)(t1 / (double)M), (float)(t2 / (double)M), A, B);
+      s_co[4 * C + c] = A; s_co[5 * C + c] = B;
+      if (blockIdx.x == 0) {
+        // d beta = sum dz, d gamma = sum dz * xhat; the conv bias in front of the BatchNorm has gradient sum(dy) == 0
+        if (p.dbeta) p.dbeta[c] = (float)t1;
+        if (p.dgamma) p.dgamma[c] = (float)t2;
+        if (p.dbias) p.dbias[c] = 0.f;
       }
-#pragma unroll
-      for (int r = 0; r < NUNET_BN_SUM_REPLICAS; ++r) { t1 += q1[r]; t2 += q2[r]; }
-      s_co[4 * C + c] = t1 / M; s_co[5 * C + c] = t2 / M;
     }
   }
   __syncthreads();
-  float sc[EPV], sh[EPV], mean[EPV], istd[EPV], k1[EPV], k2[EPV];
+  __attribute__((aligned(16))) float sc[EPV], sh[EPV], mean[EPV], istd[EPV], k1[EPV], k2[EPV];   // APPLY: k1, k2 hold A, B (bn_bwd_AB)
 #pragma unroll
   for (int e = 0; e < EPV; ++e) {
     const int c = cg * EPV + e;
     mean[e] = s_co[c]; istd[e] = s_co[C + c]; sc[e] = s_co[2 * C + c]; sh[e] = s_co[3 * C + c];
     if constexpr (APPLY) { k1[e] = s_co[4 * C + c]; k2[e] = s_co[5 * C + c]; }
   }
-  float a1[EPV], a2[EPV];
+  float a1[APPLY ? 1 : EPV], a2[APPLY ? 1 : EPV];
+  if constexpr (!APPLY) {
 #pragma unroll
-  for (int e = 0; e < EPV; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    for (int e = 0; e < EPV; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  }
   while (pix0 < npix) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t pix = pix0 + u * stride;
       if (pix < npix) {
-        Vec16<T> o;
+        if constexpr (APPLY) {
+          typedef typename FV<T>::type V;
+          st16((T*)p.dy + pix * p.PDY + cg * EPV,
+               vec_from_f<T>(bn_relu_bwd_apply<V>(vec_to_f<T>(vd[u]), vec_to_f<T>(vy[u]), ldf<T>(sc), ldf<T>(sh), ldf<T>(k1), ldf<T>(k2))));
+        } else {
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-          const float yv = vy[u].get(e);
-          const float act = yv * sc[e] + sh[e];
-          const float dz = act > 0.f ? vd[u].get(e) : 0.f;
-          const float xh = (yv - mean[e]) * istd[e];
-          if constexpr (APPLY) {
-            const float dyv = sc[e] * (dz - k1[e] - xh * k2[e]);
-            o.set(e, dyv);
-            a1[e] += to_f32(from_f32<T>(dyv));   // the stored (rounded) value; not o.get(e): see bn_relu_fwd_kernel
-          } else {
-            a1[e] += dz;
-            a2[e] += dz * xh;
+          for (int e = 0; e < EPV; ++e) {
+            const float yv = vy[u].get(e);
+            const float act = __builtin_fmaf(yv, sc[e], sh[e]);
+            const float dz = act > 0.f ? vd[u].get(e) : 0.f;
+            const float xh = (yv - mean[e]) * istd[e];
+            a1[e] += dz; a2[e] += dz * xh;
           }
         }
-        if constexpr (APPLY) st16((T*)p.dy + pix * p.PDY + cg * EPV, o);
       }
     }
     pix0 += U * stride;
     if (pix0 < npix) load_batch(pix0);
   }
-  // block reduction over the ppb threads that share a channel group, then one atomic per channel
+  if constexpr (!APPLY) {
+    // block reduction over the ppb threads that share a channel group (fixed order), then one fixed-point add per channel
 #pragma unroll
-  for (int e = 0; e < EPV; ++e) {
-    s_part[(threadIdx.x * NV + 0) * EPV + e] = a1[e];
-    if constexpr (!APPLY) s_part[(threadIdx.x * NV + 1) * EPV + e] = a2[e];
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < NV * C; t += blockDim.x) {
-    const int v = t / C, c = t - v * C;
-    const int g = c / EPV, e = c - g * EPV;
-    float sum = 0.f;
-    for (int q = 0; q < ppb; ++q) sum += s_part[((q * G + g) * NV + v) * EPV + e];
-    if constexpr (APPLY) { if (p.dbias) atomicAdd(&p.dbias[c], sum); }
-    else atomicAdd(&p.sums[((blockIdx.x & (bn_sum_replicas(C) - 1)) * 2 + v) * C + c], sum);
-  }
-  if constexpr (APPLY) {
-    if (blockIdx.x == 0) {
-      for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        if (p.dbeta) p.dbeta[c] += s_co[4 * C + c] * M;
-        if (p.dgamma) p.dgamma[c] += s_co[5 * C + c] * M;
-      }
+    for (int e = 0; e < EPV; ++e) {
+      s_part[(threadIdx.x * NV + 0) * EPV + e] = a1[e];
+      s_part[(threadIdx.x * NV + 1) * EPV + e] = a2[e];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NV * C; t += blockDim.x) {
+      const int v = t / C, c = t - v * C;
+      const int g = c / EPV, e = c - g * EPV;
+      float sum = 0.f;
+      for (int q = 0; q < ppb; ++q) sum += s_part[((q * G + g) * NV + v) * EPV + e];
+      fx_add(p.sums + ((size_t)((blockIdx.x & (bn_sum_replicas(C) - 1)) * 2 + v) * C + c) * NUNET_FX_WORDS, sum);
     }
   }
 }
@@ -454,7 +407,7 @@ static int bn_bwd_cap(bool apply) {
 template <typename T, bool APPLY> static int launch_bn_bwd_t(const nunet_bn_bwd_desc* d, hipStream_t st) {
   BnBwdP p;
   p.da = d->da; p.PDA = d->PDA; p.y = d->y; p.PY = d->PY; p.mi = d->mean_invstd; p.gamma = d->gamma; p.beta = d->beta;
-  p.sums = d->sums; p.dgamma = d->dgamma; p.dbeta = d->dbeta; p.dbias = d->dbias; p.dy = d->dy; p.PDY = d->PDY;
+  p.sums = (long long*)d->sums; p.dgamma = d->dgamma; p.dbeta = d->dbeta; p.dbias = d->dbias; p.dy = d->dy; p.PDY = d->PDY;
   p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C;
   const int G = d->C / Tr<T>::EPV;
   const int64_t np = (int64_t)d->N * d->H * d->W;
@@ -758,9 +711,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   constexpr int EPV = Tr<T>::EPV;
   constexpr int G = 32 / EPV;
   constexpr int KM = KT > 0 ? KT : HEAD_MAXK;
-  __shared__ float s_dw[HEAD_MAXK * 32 + HEAD_MAXK];
-  for (int i = threadIdx.x; i < HEAD_MAXK * 33; i += blockDim.x) s_dw[i] = 0.f;
-  __syncthreads();
+  __shared__ float s_dw[4 * (HEAD_MAXK * 32 + HEAD_MAXK)];   // per wave
   const int cg = threadIdx.x % G, pl = threadIdx.x / G, ppb = blockDim.x / G;
   float wk[KM][EPV], aw[KM][EPV], ab[KM];
 #pragma unroll
@@ -814,19 +765,32 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
       }
     }
   }
+  // block reduction in a fixed order (bit-reproducible): lanes that own the same channel group are summed with
+  // xor-shuffles, the four waves through LDS
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < KM; ++k) {
     if (k < K) {
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) atomicAdd(&s_dw[k * 32 + cg * EPV + e], aw[k][e]);
-      if (cg == 0) atomicAdd(&s_dw[HEAD_MAXK * 32 + k], ab[k]);
+      for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) aw[k][e] += __shfl_xor(aw[k][e], off);
+        ab[k] += __shfl_xor(ab[k], off);
+      }
+      if (lane < G) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) s_dw[wv * (HEAD_MAXK * 33) + k * 32 + lane * EPV + e] = aw[k][e];
+        if (lane == 0) s_dw[wv * (HEAD_MAXK * 33) + HEAD_MAXK * 32 + k] = ab[k];
+      }
     }
   }
   __syncthreads();
   // per-block slab [K*32 weights | K biases]: plain stores, summed by the caller (no same-address atomics)
   float* slab = dw + (size_t)blockIdx.x * (K * 33);
-  for (int i = threadIdx.x; i < K * 32; i += blockDim.x) slab[i] = s_dw[i];
-  if (threadIdx.x < K) slab[K * 32 + threadIdx.x] = s_dw[HEAD_MAXK * 32 + threadIdx.x];
+  for (int i = threadIdx.x; i < K * 33; i += blockDim.x) {
+    const int j = i < K * 32 ? i : HEAD_MAXK * 32 + (i - K * 32);
+    slab[i] = (s_dw[j] + s_dw[HEAD_MAXK * 33 + j]) + (s_dw[2 * HEAD_MAXK * 33 + j] + s_dw[3 * HEAD_MAXK * 33 + j]);
+  }
 }
 template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* b, float* logits, hipStream_t st) {
   ProfScope ps(PC_HEAD, 2.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) + K * 4), st);
@@ -859,6 +823,7 @@ extern "C" int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, in
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+constexpr int BCE_GX = 64;      // most blocks per image
 __global__ __launch_bounds__(256) void bce_dice_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, float* __restrict__ ws, int N) {
   const int n = blockIdx.y;
   const float* xs = x + (int64_t)n * per;
@@ -875,20 +840,25 @@ __global__ __launch_bounds__(256) void bce_dice_partial_kernel(const float* __re
   const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { s[wv][0] = a0; s[wv][1] = a1; s[wv][2] = a2; s[wv][3] = a3; }
   __syncthreads();
-  if (threadIdx.x < 4) {
-    const float v = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
-    if (threadIdx.x < 3) atomicAdd(&ws[n * 3 + threadIdx.x], v);
-    else atomicAdd(&ws[N * 3], v);
-  }
+  // per-block partials to a slab (plain stores; the final kernel sums them in a fixed order: bit-reproducible)
+  if (threadIdx.x < 4)
+    ws[3 * N + 1 + ((size_t)n * BCE_GX + blockIdx.x) * 4 + threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
 }
-__global__ void bce_dice_final_kernel(const float* __restrict__ ws, int N, int64_t per, float* __restrict__ loss) {
-  // single wave
-  float d = 0.f;
-  for (int n = threadIdx.x; n < N; n += 64) d += (2.f * ws[n * 3] + 1e-5f) / (ws[n * 3 + 1] + ws[n * 3 + 2] + 1e-5f);
-  d = wave_sum(d);
-  if (threadIdx.x == 0) {
-    const float bce = ws[N * 3] / ((float)N * (float)per);
-    loss[0] = 0.5f * bce + (1.f - d / (float)N);
+__global__ void bce_dice_final_kernel(float* __restrict__ ws, int N, int gx, int64_t per, float* __restrict__ loss) {
+  // single wave: lane l holds partial l of image n (gx <= 64)
+  const int l = threadIdx.x;
+  float bce = 0.f, d = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float* q = ws + 3 * N + 1 + ((size_t)n * BCE_GX + l) * 4;
+    float v0 = l < gx ? q[0] : 0.f, v1 = l < gx ? q[1] : 0.f, v2 = l < gx ? q[2] : 0.f, v3 = l < gx ? q[3] : 0.f;
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3);   // (butterfly: every lane holds the totals)
+    if (l == 0) { ws[n * 3] = v0; ws[n * 3 + 1] = v1; ws[n * 3 + 2] = v2; }
+    bce += v3;
+    d += (2.f * v0 + 1e-5f) / (v1 + v2 + 1e-5f);
+  }
+  if (l == 0) {
+    ws[N * 3] = bce;
+    loss[0] = 0.5f * (bce / ((float)N * (float)per)) + (1.f - d / (float)N);
   }
 }
 __global__ __launch_bounds__(256) void bce_dice_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, const float* __restrict__ ws, const float* __restrict__ gscale, float* __restrict__ dx, int N) {
@@ -909,15 +879,14 @@ __global__ __launch_bounds__(256) void bce_dice_bwd_kernel(const float* __restri
     ds[i] = g * (kb * (pv - tv) - invN * ddice);
   }
 }
-extern "C" size_t nunet_bce_dice_ws_bytes(int32_t N) { return (size_t)(3 * N + 1) * sizeof(float); }
+extern "C" size_t nunet_bce_dice_ws_bytes(int32_t N) { return (size_t)(3 * N + 1 + (size_t)N * BCE_GX * 4) * sizeof(float); }
 extern "C" int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int64_t per, float* ws, float* loss, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && loss && N > 0 && per > 0, "bce_dice_fwd: bad args");
   hipStream_t st = (hipStream_t)s;
-  { int rc = nunet_zero_async(ws, nunet_bce_dice_ws_bytes(N), st); if (rc) return rc; }
-  const int gx = grid_for(per, 256 * 4, 64);
+  const int gx = grid_for(per, 256 * 4, BCE_GX);
   ProfScope ps(PC_LOSS, 0, (double)N * per * 8, st);
   hipLaunchKernelGGL(bce_dice_partial_kernel, dim3(gx, N), dim3(256), 0, st, logits, target, per, ws, N);
-  hipLaunchKernelGGL(bce_dice_final_kernel, dim3(1), dim3(64), 0, st, ws, N, per, loss);
+  hipLaunchKernelGGL(bce_dice_final_kernel, dim3(1), dim3(64), 0, st, ws, N, gx, per, loss);
   return nunet_check_launch("bce_dice_fwd");
 }
 extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per, const float* ws, const float* gscale, float* dlogits, nunet_stream_t s) {

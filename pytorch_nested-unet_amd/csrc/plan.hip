@@ -378,53 +378,6 @@ __global__ __launch_bounds__(512) void update_kernel(UpdP u, T* __restrict__ are
   }
 }
 
-// unpack_kernel with the optimiser step as its epilogue: the gradient is gathered from the native-layout scratch and
-// consumed on the spot (no OIHW gradient round trip, one launch less); `u.grads` optionally still receives it.
-__global__ __launch_bounds__(256) void unpack_sgd_kernel(UpdP u, UnpackTab tab) {
-  const UnpackEnt en = tab.e[blockIdx.y];
-  const float* dw = u.scratch + en.src;
-  const float lr = u.lr[0];
-  const long long nw = (long long)en.cout * en.cin * en.taps;
-  const long long total = nw + (long long)en.nvec * en.cout;
-  if (en.nslab > 1) {
-    if (blockIdx.x != 0) return;
-    for (int e = threadIdx.x; e < (int)total; e += blockDim.x) {   // 1x1 head: slabs summed in fixed order
-      float g = 0.f;
-      for (int sl = 0; sl < en.nslab; ++sl) g += dw[(long long)sl * total + e];
-      g *= u.gscale;
-      const long long idx = en.dst + e;
-      if (u.grads) u.grads[idx] = g;
-      float m = u.mom[idx];
-      const float pn = sgd_one(u.params[idx], g, &m, u, lr);
-      u.mom[idx] = m; u.params[idx] = pn;
-    }
-    return;
-  }
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    float g;
-    if (i < nw) {
-      int tap, ci, co;
-      if (en.fast) {
-        const int ii = (int)i, t = dec_div(ii, en.inv_taps);
-        tap = ii - t * en.taps; co = dec_div(t, en.inv_cin); ci = t - co * en.cin;
-      } else {
-        tap = (int)(i % en.taps);
-        const long long t = i / en.taps;
-        ci = (int)(t % en.cin); co = (int)(t / en.cin);
-      }
-      g = dw[((long long)tap * en.cout + co) * en.cinpad + ci];
-    } else {
-      g = dw[(long long)en.taps * en.cout * en.cinpad + (i - nw)];
-    }
-    g *= u.gscale;
-    const long long idx = en.dst + i;
-    if (u.grads) u.grads[idx] = g;
-    float m = u.mom[idx];
-    const float pn = sgd_one(u.params[idx], g, &m, u, lr);
-    u.mom[idx] = m; u.params[idx] = pn;
-  }
-}
-
 template <typename T> static int launch_pack(const float* params, void* arena_t, PackTab& tab, long long maxn, hipStream_t st) {
   (void)maxn;
   int nt = 0;
@@ -474,7 +427,8 @@ struct ConvL {
   long long rm_off, rv_off; int bn_index; // floats into bnbuf / index into nbt
   long long wf, wd;                       // elements of T into the packed-weight region (wd -1: none)
   long long gs;                           // floats into grad scratch: [dw 9*cout*cinpad][db][dgamma][dbeta]
-  long long stats, save, bsum;            // floats into the fp32 small-vector regions
+  long long stats, save, bsum;            // floats into the fp32 small-vector regions (x REPLICAS x 2 int64 words in the fixed-point regions)
+  long long slab; int ks, wg_target;      // weight-gradient K-split slabs: floats into the slab region, slices, workgroup target
 };
 struct Node {
   int i, j;
@@ -496,9 +450,7 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   bool lanes_external;
   std::vector<hipStream_t> cap_streams;   // never-reused streams for capture-time lane continuation
   size_t cap_next;
-  void* gs_clean_arena;
-  void* sk_ready_arena;                    // arena whose K-split arrival counters have been zeroed
-  bool bwd_written[5][5]; int bwd_pp[5];   // state carried between backward phases   // arena whose gradient scratch was cleared by the last training forward
+  bool bwd_written[5][5]; int bwd_pp[5];   // state carried between backward phases
   // NUNET_STAMPS=1 diagnostic: a 1-thread kernel after every scheduled op writes the 100 MHz wall clock,
   // so the real timeline of an (unprofiled) hipGraph replay can be read back (tools/stamp_timeline.py)
   unsigned long long* stamps;              // device, [2][STAMP_CAP]
@@ -523,8 +475,9 @@ struct nunet_plan {
   long long nparams, nbnbuf; int nbn;
   int first_phase_nodes; long long gs_bucket0;   // backward phase 1 = heads + this many last nodes; its gradient-scratch prefix
   // arena regions (byte offsets)
-  size_t off_stats, stats_floats;
-  size_t off_gs, gs_floats;     // grad scratch + bn-bwd sums (zeroed every backward)
+  size_t off_fx, stats_floats;  // fixed-point per-channel sums: [BatchNorm statistics | BatchNorm-backward sums], zeroed by every training forward
+  size_t off_gs, gs_floats;     // reduced gradient scratch (native layout, gradient-ready order): what a data-parallel job exchanges
+  size_t off_slab; long long slab_floats;   // K-split slabs of the weight gradients (summed into the scratch by reduce_kernel)
   size_t off_save;
   size_t off_wpack; long long wpack_elems;
   size_t off_img;
@@ -538,6 +491,10 @@ struct nunet_plan {
   UnpackTab utab; long long unpack_maxn;
 };
 
+static size_t fx_region_bytes(const nunet_plan* P) { return P->stats_floats * NUNET_BN_SUM_REPLICAS * NUNET_FX_WORDS * sizeof(long long); }
+static long long* fx_of(void* arena, const nunet_plan* P, int region, long long off) {   // region 0: BN statistics, 1: BN-backward sums
+  return (long long*)((char*)arena + P->off_fx + (size_t)region * fx_region_bytes(P)) + off * NUNET_BN_SUM_REPLICAS * NUNET_FX_WORDS;
+}
 static size_t bump(size_t& cur, size_t bytes) {
   size_t o = align_up(cur, 256);
   cur = o + bytes;
@@ -626,11 +583,22 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   }
   P->first_phase_nodes = unet ? 4 : 5;
   P->gs_bucket0 = 0;
+  long long slab = 0;
+  int ks_max = 0;
+  { const char* e = getenv("NUNET_WG_KS_MAX"); ks_max = e ? atoi(e) : 0; }
   for (int k = (int)P->exec.size() - 1; k >= 0; --k) {
     Node& n = P->exec[k];
     for (int cv = 1; cv >= 0; --cv) {
       ConvL& c = cv ? n.c2 : n.c1;
       c.gs = gs; gs += 9LL * c.cout * c.cinpad + 3LL * c.cout;
+      // K-split of the weight gradient: the two problems of a block share one launch, the one with fewer input
+      // channels takes half the workgroups (fewer, fatter slices: less slab traffic)
+      const ConvL& o = cv ? n.c1 : n.c2;
+      c.wg_target = c.cinpad < o.cinpad ? 128 : 256;
+      nunet_wgrad_desc wd; memset(&wd, 0, sizeof(wd));
+      wd.N = cfg->N; wd.H = P->hl[n.i]; wd.W = P->wl[n.i]; wd.C0 = c.cinpad; wd.Cout = c.cout; wd.target_wgs = c.wg_target; wd.max_slabs = ks_max;
+      c.ks = nunet_conv3x3_wgrad_slabs(&wd);
+      c.slab = slab; slab += (long long)c.ks * 9LL * c.cout * c.cinpad;
     }
     if (k == (int)P->exec.size() - P->first_phase_nodes) P->gs_bucket0 = gs;
   }
@@ -640,9 +608,11 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   // ---- arena ---------------------------------------------------------------------
   size_t cur = 0;
   P->stats_floats = (size_t)sv;
-  P->off_stats = bump(cur, P->stats_floats * 4 * NUNET_BN_SUM_REPLICAS);   // replicated per-channel sums
-  P->gs_floats = (size_t)gs + (size_t)sv * NUNET_BN_SUM_REPLICAS;  // grad scratch followed by the (replicated) bn-bwd sums
+  P->off_fx = bump(cur, 2 * fx_region_bytes(P));   // [forward statistics | backward sums], replicated fixed-point accumulators
+  P->gs_floats = (size_t)gs;
   P->off_gs = bump(cur, P->gs_floats * 4);
+  P->slab_floats = slab;
+  P->off_slab = bump(cur, (size_t)slab * 4);
   P->off_save = bump(cur, (size_t)sv * 4);
   P->off_wpack = bump(cur, (size_t)wp * P->es);
   P->off_img = bump(cur, (size_t)P->px[0] * 32 * P->es);
@@ -668,11 +638,10 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   }
   // K-split slabs for the grid-starved levels 3 and 4 (up to 8 slices of the widest output at the
   // level); deterministic (fixed summation order). Measured +1.2 % on the bench; NUNET_SPLITK=0 disables.
-  const char* ske = getenv("NUNET_SPLITK");
-  const bool sk_on = !ske || atoi(ske) != 0;
+  const bool sk_on = true;
   for (int i = 0; i < 5; ++i) {
     const int maxc = (i < 3 || !sk_on) ? 0 : (i < 4 ? (4 - i) * NBF[i] + NBF[i + 1] : NBF[4]);
-    P->sk_floats[i] = 8LL * P->px[i] * maxc + NUNET_SPLITK_COUNTER_FLOATS;   // arrival counters + up to 8 slabs
+    P->sk_floats[i] = 8LL * P->px[i] * maxc;   // up to 8 slabs
     P->off_sk[i] = bump(cur, (size_t)P->sk_floats[i] * 4 + 16);
   }
   P->total = align_up(cur, 256);
@@ -709,8 +678,6 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->lanes_ok = true;
   rt->lanes_external = false;
   rt->cap_next = 0;
-  rt->gs_clean_arena = nullptr;
-  rt->sk_ready_arena = nullptr;
   rt->stamps = nullptr;
   rt->b0_event = nullptr; rt->b0_enabled = false;
   rt->events_used[0] = rt->events_used[1] = 0;
@@ -820,6 +787,7 @@ struct Sched {
     if (!ev || ev_st == st) return;
     for (int k = 0; k < npend; ++k) if (pend[k] == ev) return;
     if (npend < 64) pend[npend++] = ev;
+    else failed = true;        // a dropped wait would be a silent race between lanes: reported by the caller after the join
   }
   // ROCm 7.2: inside a stream capture, a stream that waits on an event DESCENDING from its
   // own tail node crashes hipStreamEndCapture (tools/capture_patterns3.py "pp1"). The x_{i,j}
@@ -833,8 +801,8 @@ struct Sched {
   // begin an op on `lane` reading `rd` and writing `wr` resources; returns the stream to launch on
   hipStream_t begin(int lane, std::initializer_list<int> rd, std::initializer_list<int> wr) {
     int r[16], w[16], nr = 0, nw = 0;
-    for (int x : rd) if (x >= 0 && nr < 16) r[nr++] = x;
-    for (int x : wr) if (x >= 0 && nw < 16) w[nw++] = x;
+    for (int x : rd) if (x >= 0) { if (nr < 16) r[nr++] = x; else failed = true; }
+    for (int x : wr) if (x >= 0) { if (nw < 16) w[nw++] = x; else failed = true; }
     return begin_v(lane_map[lane], r, nr, w, nw);
   }
   hipStream_t begin_v(int lane, const int* rd, int nrd, const int* wr, int nwr) {   // `lane` already mapped
@@ -870,28 +838,20 @@ struct Sched {
     return st;
   }
 
-  // ---- deferred ops + list scheduling ------------------------------------------------------
-  // ROCm resolves a cross-queue dependency of a graph node against what has ALREADY been placed on
-  // the producer's queue, so the order in which ops are issued (captured) decides when a side block
-  // can start: issuing the x_{i,j} grid block by block left three lanes idle for the first third of
-  // the backward pass (profiles/r01_summary.md). Ops are therefore collected first, then issued in
-  // the order of a simulated list schedule (earliest start, longest remaining path first). `leaf`
-  // ops (weight gradients: nothing but the final unpack consumes them) float to whichever lane is
-  // idle. Conflicting ops (RAW/WAW/WAR on a resource) keep their program order, so the events
-  // derived at issue time are the ones program order would give.
+  // ---- deferred ops: the backward pass collects its ops first (descriptors captured by value), then issues them
   struct Op { int lane, leaf; float cost; int nrd, nwr; int rd[12], wr[8]; char name[32]; std::function<int(hipStream_t)> fn; };
   std::vector<Op> ops;
   void add(int lane, int leaf, float cost, std::initializer_list<int> rd, std::initializer_list<int> wr, std::function<int(hipStream_t)> fn) {
     Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0;
-    for (int x : rd) if (x >= 0 && o.nrd < 12) o.rd[o.nrd++] = x;
-    for (int x : wr) if (x >= 0 && o.nwr < 8) o.wr[o.nwr++] = x;
+    for (int x : rd) if (x >= 0) { if (o.nrd < 12) o.rd[o.nrd++] = x; else failed = true; }
+    for (int x : wr) if (x >= 0) { if (o.nwr < 8) o.wr[o.nwr++] = x; else failed = true; }
     memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
     o.fn = std::move(fn);
     ops.push_back(std::move(o));
   }
   void add_v(int lane, int leaf, float cost, const int* rd, int nrd, std::function<int(hipStream_t)> fn) {
     Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0;
-    for (int q = 0; q < nrd; ++q) if (rd[q] >= 0 && o.nrd < 12) o.rd[o.nrd++] = rd[q];
+    for (int q = 0; q < nrd; ++q) if (rd[q] >= 0) { if (o.nrd < 12) o.rd[o.nrd++] = rd[q]; else failed = true; }
     memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
     o.fn = std::move(fn);
     ops.push_back(std::move(o));
@@ -978,91 +938,12 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
 }
 
 int Sched::run_ops() {
-  const int n = (int)ops.size();
+  // ops are issued in program order (a simulated list schedule and a rewrite of the captured graph's edge order were
+  // both measured slower than the plain capture order on ROCm 7.2, see DESIGN.md, and are not kept)
   int rc = NUNET_OK;
-  static int listsched = -1;
-  if (listsched < 0) { const char* e = getenv("NUNET_LISTSCHED"); listsched = e ? atoi(e) : 0; }
-  std::vector<int> order; order.reserve(n);
-  std::vector<int> on_lane(n);
-  for (int j = 0; j < n; ++j) on_lane[j] = ops[j].lane;
-  if (!multi || !listsched || n < 3) {
-    for (int j = 0; j < n; ++j) order.push_back(j);
-  } else {
-    // dependency edges from program order
-    std::vector<std::vector<int>> deps(n), succ(n);
-    {
-      std::vector<int> lastw(NRES, -1);
-      std::vector<std::vector<int>> rds(NRES);
-      for (int j = 0; j < n; ++j) {
-        auto dep = [&](int d) { if (d >= 0 && d != j) { for (int x : deps[j]) if (x == d) return; deps[j].push_back(d); succ[d].push_back(j); } };
-        for (int q = 0; q < ops[j].nrd; ++q) dep(lastw[ops[j].rd[q]]);
-        for (int q = 0; q < ops[j].nwr; ++q) { const int r = ops[j].wr[q]; dep(lastw[r]); for (int x : rds[r]) dep(x); }
-        for (int q = 0; q < ops[j].nrd; ++q) rds[ops[j].rd[q]].push_back(j);
-        for (int q = 0; q < ops[j].nwr; ++q) { const int r = ops[j].wr[q]; lastw[r] = j; rds[r].clear(); }
-      }
-    }
-    std::vector<float> bl(n, 0.f);   // longest path to a sink, own cost included
-    for (int j = n - 1; j >= 0; --j) { float m = 0.f; for (int x : succ[j]) m = bl[x] > m ? bl[x] : m; bl[j] = ops[j].cost + m; }
-    int nl = 4;
-    for (int j = 0; j < n; ++j) if (ops[j].lane + 1 > nl) nl = ops[j].lane + 1;
-    if (nl > NLANES) nl = NLANES;
-    const float XL = 6.f;            // dispatch latency of an edge that crosses hardware queues (us)
-    std::vector<float> fin(n, 0.f), lane_free(nl, 0.f);
-    std::vector<char> done(n, 0);
-    std::vector<int> ndep(n);
-    int nonleaf_left = 0;
-    for (int j = 0; j < n; ++j) { ndep[j] = (int)deps[j].size(); if (!ops[j].leaf) ++nonleaf_left; }
-    auto ready_at = [&](int j, int L) { float r = 0.f; for (int d : deps[j]) { float f = fin[d] + (on_lane[d] != L ? XL : 0.f); r = f > r ? f : r; } return r; };
-    float t = 0.f;
-    int left = n;
-    while (left > 0) {
-      bool progress = false;
-      for (int L = 0; L < nl; ++L) {
-        if (lane_free[L] > t) continue;
-        int best = -1; bool best_leaf = true; float best_bl = -1.f;
-        for (int j = 0; j < n; ++j) {
-          if (done[j] || ndep[j] > 0) continue;
-          const bool leaf = ops[j].leaf != 0;
-          if (!leaf && ops[j].lane != L) continue;
-          if (leaf && L == 0 && nonleaf_left > 0) continue;          // keep the critical-chain lane free
-          if (ready_at(j, L) > t) continue;
-          if (best < 0 || (best_leaf && !leaf) || (best_leaf == leaf && bl[j] > best_bl)) { best = j; best_leaf = leaf; best_bl = bl[j]; }
-        }
-        if (best >= 0 && best_leaf) {
-          // do not start a long leaf just before an op of this lane becomes ready
-          for (int j = 0; j < n && best >= 0; ++j)
-            if (!done[j] && ndep[j] == 0 && !ops[j].leaf && ops[j].lane == L && ready_at(j, L) < t + 0.5f * ops[best].cost) best = -1;
-        }
-        if (best < 0) continue;
-        done[best] = 1; --left; if (!ops[best].leaf) --nonleaf_left;
-        on_lane[best] = L; fin[best] = t + ops[best].cost; lane_free[L] = fin[best];
-        for (int x : succ[best]) --ndep[x];
-        order.push_back(best);
-        progress = true;
-      }
-      if (progress) continue;
-      float nt = 1e30f;
-      for (int L = 0; L < nl; ++L) if (lane_free[L] > t && lane_free[L] < nt) nt = lane_free[L];
-      for (int j = 0; j < n; ++j) {
-        if (done[j] || ndep[j] > 0) continue;
-        for (int L = 0; L < nl; ++L) {
-          if (!ops[j].leaf && ops[j].lane != L) continue;
-          float r = ready_at(j, L); if (r < lane_free[L]) r = lane_free[L];
-          if (r > t && r < nt) nt = r;
-        }
-      }
-      if (nt > 1e29f) nt = t + 1.f;     // cannot happen for a valid program order; keeps the loop finite
-      t = nt;
-      if (t > 1e7f) break;
-    }
-    if (left > 0) { order.clear(); for (int j = 0; j < n; ++j) { order.push_back(j); on_lane[j] = ops[j].lane; } }
-    if (getenv("NUNET_SCHED_DUMP")) {
-      for (int j : order) fprintf(stderr, "sched %3d lane %d leaf %d cost %6.1f start %8.1f bl %7.1f\n", j, on_lane[j], ops[j].leaf, ops[j].cost, fin[j] - ops[j].cost, bl[j]);
-    }
-  }
-  for (int q = 0; q < n && rc == NUNET_OK; ++q) {
-    Op& o = ops[order[q]];
-    hipStream_t st = begin_v(on_lane[order[q]], o.rd, o.nrd, o.wr, o.nwr);
+  for (size_t q = 0; q < ops.size() && rc == NUNET_OK; ++q) {
+    Op& o = ops[q];
+    hipStream_t st = begin_v(o.lane, o.rd, o.nrd, o.wr, o.nwr);
     rc = o.fn(st);
     memcpy(cur_name, o.name, sizeof(cur_name));
     end();
@@ -1101,41 +982,17 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   hipStream_t st = (hipStream_t)s;
   const nunet_plan_cfg& c = P->cfg;
   const int dt = c.dtype, es = P->es;
-  float* stats = (float*)AB(arena, P->off_stats);
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
-  // prerequisites of everything on the caller's stream, before the fork
-  // NUNET_PREP_LANE=1: statistics zero + input layout run on lane 1 beside the weight pack on lane 0 instead of ahead
-  // of the fork (every conv descends from B00.conv1, which reads R_IMG, so the zeroed statistics are ordered too)
-  static int prep_lane = -1;
-  if (prep_lane < 0) { const char* e = getenv("NUNET_PREP_LANE"); prep_lane = e ? atoi(e) : 0; }
-  auto prep = [&](hipStream_t ps) -> int {
-    if (training) CK(nunet_zero_async(stats, P->stats_floats * 4 * NUNET_BN_SUM_REPLICAS, ps));
-    if (rt_of(P)->sk_ready_arena != arena) {   // K-split arrival counters: zero once, every launch leaves them zero
-      for (int l = 0; l < 5; ++l)
-        if (P->sk_floats[l] > 0) CK(nunet_zero_async(AB(arena, P->off_sk[l]), NUNET_SPLITK_COUNTER_FLOATS * 4, ps));
-      rt_of(P)->sk_ready_arena = arena;
-    }
-    CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, (nunet_stream_t)ps));
-    return NUNET_OK;
-  };
-  if (!prep_lane) CK(prep(st));
+  // prerequisites of everything on the caller's stream, before the fork: both fixed-point sum regions (the
+  // BatchNorm statistics of this pass and the BatchNorm-backward sums of the pass that may follow) in one launch
+  if (training) CK(nunet_zero_async(AB(arena, P->off_fx), 2 * fx_region_bytes(P), st));
+  CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, (nunet_stream_t)st));
 
   Sched S; S.init(P, st, 0);
   int rc = NUNET_OK;
-  if (prep_lane) {
-    S.name("prep");
-    hipStream_t ls = S.begin(1, {}, {R_IMG, R_SK + 0, R_SK + 1, R_SK + 2, R_SK + 3, R_SK + 4});
-    rc = prep(ls);
-    S.end();
-  }
-  // Measured on MI355X: repacking the weights per level on the lanes (NUNET_PACK_LANES=1) is 9 %
-  // SLOWER than one pack launch ahead of the lanes; clearing the gradient scratch on a lane during
-  // forward (NUNET_GS_FWD=1) is neutral. Both stay off by default.
-  static int pack_lanes = -1, gs_fwd = -1;
-  if (pack_lanes < 0) { const char* e = getenv("NUNET_PACK_LANES"); pack_lanes = e ? atoi(e) : 0; e = getenv("NUNET_GS_FWD"); gs_fwd = e ? atoi(e) : 0; }
   const bool skip_pack = (training_flags & 2) != 0;   // the caller vouches that nunet_plan_update / _repack left the packed weights current
-  if (!pack_lanes && !skip_pack) {
+  if (!skip_pack) {
     S.name("pack");
     hipStream_t ls = S.begin(0, {}, {R_WP + 0, R_WP + 1, R_WP + 2, R_WP + 3, R_WP + 4});
     if (dt == NUNET_F32) rc = launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, ls);
@@ -1143,27 +1000,11 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
     else rc = launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
     S.end();
   }
-  for (int l = 0; l < 5 && rc == NUNET_OK && pack_lanes && !skip_pack; ++l) {
-    if (P->ptab_lvl[l].n == 0) continue;
-    // 1: each level on its own lane; 2: level 0 on the chain lane (needed first), the rest one after the other on lane 3
-    S.name("pack%d", l);
-    hipStream_t ls = S.begin(pack_lanes == 2 ? (l == 0 ? 0 : 3) : l, {}, {R_WP + l});
-    if (dt == NUNET_F32) rc = launch_pack<float>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);
-    else if (dt == NUNET_BF16) rc = launch_pack<bf16_t>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);
-    else rc = launch_pack<f16_t>(params, wpack, P->ptab_lvl[l], P->pack_maxn_lvl[l], ls);
-    S.end();
-  }
-  if (training && rc == NUNET_OK && gs_fwd) {
-    // the gradient scratch of the coming backward is cleared here, on the least loaded lane
-    hipStream_t ls = S.begin(4, {}, {R_GS});
-    rc = nunet_zero_async(AB(arena, P->off_gs), P->gs_floats * 4, ls);
-    S.end();
-    rt_of(P)->gs_clean_arena = arena;
-  }
   for (size_t k = 0; k < P->exec.size() && rc == NUNET_OK; ++k) {
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
     const int lane = lane_of(P, n), rb = R_BLK + (int)k * B_STRIDE;
+    const int rskf = P->sk_floats[i] > 0 ? R_SK + i : -1;
     if (n.up_slot >= 0) {
       S.name("B%d%d.upF", n.i, n.j);
       hipStream_t ls = S.begin(lane, {R_X + (i + 1) * 5 + n.up_slot}, {rb + B_UP});
@@ -1173,17 +1014,14 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       S.end();
       if (rc) break;
     }
-    for (int cv = 0; cv < 2 && rc == NUNET_OK; ++cv) {
-      const ConvL& L = cv == 0 ? n.c1 : n.c2;
+    // ---- conv1: raw output y1 + its BatchNorm sums (fixed point) ---------------------------------------------
+    {
+      const ConvL& L = n.c1;
       nunet_conv_desc d; memset(&d, 0, sizeof(d));
       d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
       hipStream_t ls;
-      const int rskf = P->sk_floats[i] > 0 ? R_SK + i : -1;
-      S.name("B%d%d.conv%d", n.i, n.j, cv + 1);
-      if (cv == 1) {
-        d.src0 = AB(arena, n.a1); d.C0 = f; d.P0 = f;
-        ls = S.begin(lane, {rb + B_A1, R_WP + i}, {rb + B_Y2, rb + B_ST2, rskf});
-      } else if (n.in_prefix == 0) {
+      S.name("B%d%d.conv1", n.i, n.j);
+      if (n.in_prefix == 0) {
         if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}); }
         else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}); }
       } else {
@@ -1193,36 +1031,58 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
                             n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf});
       }
       d.wpack = wpack + (size_t)L.wf * es;
-      d.bias = nullptr;  // absorbed by the BatchNorm that follows (see bn_channel_coeffs)
-      d.dst0 = AB(arena, cv == 0 ? n.y1 : n.y2); d.D0 = f; d.Q0 = f;
-      d.stats = training ? stats + L.stats * NUNET_BN_SUM_REPLICAS : nullptr;
+      d.bias = nullptr;  // absorbed by the BatchNorm that follows (bn_stat_coeffs)
+      d.dst0 = AB(arena, n.y1); d.D0 = f; d.Q0 = f;
+      d.stats = training ? (int64_t*)fx_of(arena, P, 0, L.stats) : nullptr;
       if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
-      g_prof_alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
+      g_prof_alg_cin = (i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
       rc = nunet_conv3x3_fwd(&d, ls);
       g_prof_alg_cin = 0;
       S.end();
       if (rc) break;
-
+    }
+    // ---- conv2: BatchNorm1 + ReLU applied to y1 on the way into LDS (archs1.py:23-28); the activation a1 is
+    // stored on the side for the weight gradient when a backward pass may follow -----------------------------------
+    {
+      const ConvL& L = n.c2; const ConvL& L1 = n.c1;
+      nunet_conv_desc d; memset(&d, 0, sizeof(d));
+      d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
+      d.src0 = AB(arena, n.y1); d.C0 = f; d.P0 = f;
+      d.in_tf = NUNET_TF_BN_RELU; d.tf_training = training;
+      d.tf_fx = training ? (const int64_t*)fx_of(arena, P, 0, L1.stats) : nullptr;
+      d.tf_gamma = params + L1.g_off; d.tf_beta = params + L1.be_off; d.tf_conv_bias = params + L1.b_off;
+      d.tf_running_mean = bnbuf + L1.rm_off; d.tf_running_var = bnbuf + L1.rv_off; d.tf_nbt = nbt ? nbt + L1.bn_index : nullptr;
+      d.tf_mean_invstd = save + L1.save; d.tf_momentum = 0.1f; d.tf_eps = 1e-5f;
+      d.tf_store = training ? AB(arena, n.a1) : nullptr; d.tf_ps = f;
+      d.wpack = wpack + (size_t)L.wf * es;
+      d.dst0 = AB(arena, n.y2); d.D0 = f; d.Q0 = f;
+      d.stats = training ? (int64_t*)fx_of(arena, P, 0, L.stats) : nullptr;
+      if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
+      S.name("B%d%d.conv2", n.i, n.j);
+      hipStream_t ls = S.begin(lane, {rb + B_Y1, rb + B_ST1, R_WP + i}, {rb + B_Y2, rb + B_ST2, rb + B_A1, rskf});
+      rc = nunet_conv3x3_fwd(&d, ls);
+      S.end();
+      if (rc) break;
+    }
+    // ---- BatchNorm2 + ReLU (+ 2x2 max-pool for the encoder column): the block output has many consumers
+    // (convs of the same level, the upsample, the pool, a head) and is materialised once in its level-buffer slot ------
+    {
+      const ConvL& L = n.c2;
       nunet_bn_fwd_desc b; memset(&b, 0, sizeof(b));
       b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
-      b.y = d.dst0; b.PY = f; b.conv_bias = params + L.b_off; b.stats = stats + L.stats * NUNET_BN_SUM_REPLICAS;
+      b.y = AB(arena, n.y2); b.PY = f; b.conv_bias = params + L.b_off; b.stats = (const int64_t*)fx_of(arena, P, 0, L.stats);
       b.gamma = params + L.g_off; b.beta = params + L.be_off;
       b.running_mean = bnbuf + L.rm_off; b.running_var = bnbuf + L.rv_off;
       b.num_batches_tracked = nbt ? nbt + L.bn_index : nullptr;
       b.save_mean_invstd = save + L.save; b.training = training; b.momentum = 0.1f; b.eps = 1e-5f;
-      S.name("B%d%d.bnF%d", n.i, n.j, cv + 1);
-      if (cv == 0) {
-        b.a = AB(arena, n.a1); b.PA = f;
-        ls = S.begin(lane, {rb + B_Y1, rb + B_ST1}, {rb + B_A1});
-      } else {
-        b.a = AB(arena, P->X[i] + (size_t)n.out_slot * f * es); b.PA = P->PX[i];
-        int rpin = -1;
-        if (n.in_prefix == 0 && i < 4) {  // encoder column: feed the next level (archs1.py:115,118,122,127)
-          const int q = blk_index(P, i + 1, 1);
-          if (q >= 0) { b.pooled = AB(arena, P->exec[q].pin); b.PP = f; rpin = R_BLK + q * B_STRIDE + B_PIN; }
-        }
-        ls = S.begin(lane, {rb + B_Y2, rb + B_ST2}, {R_X + i * 5 + n.out_slot, rpin});
+      b.a = AB(arena, P->X[i] + (size_t)n.out_slot * f * es); b.PA = P->PX[i];
+      int rpin = -1;
+      if (n.in_prefix == 0 && i < 4) {  // encoder column: feed the next level (archs1.py:115,118,122,127)
+        const int q = blk_index(P, i + 1, 1);
+        if (q >= 0) { b.pooled = AB(arena, P->exec[q].pin); b.PP = f; rpin = R_BLK + q * B_STRIDE + B_PIN; }
       }
+      S.name("B%d%d.bnF2", n.i, n.j);
+      hipStream_t ls = S.begin(lane, {rb + B_Y2, rb + B_ST2}, {R_X + i * 5 + n.out_slot, rpin});
       rc = nunet_bn_relu_fwd(&b, ls);
       S.end();
     }
@@ -1238,7 +1098,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
     }
   }
   S.join();  // always rejoin the caller's stream (also on error: a capture must not be left forked)
-  if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_forward: capture lane pool exhausted"); rc = NUNET_EINVAL; }
+  if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_forward: lane scheduler overflow (capture stream pool / dependency lists)"); rc = NUNET_EINVAL; }
   return rc;
 }
 
@@ -1251,7 +1111,7 @@ extern "C" int nunet_plan_grad_scratch(const nunet_plan* P, int64_t* byte_offset
   NUNET_REQUIRE(P && byte_offset && bucket0_floats && total_floats, "plan_grad_scratch: null pointer");
   *byte_offset = (int64_t)P->off_gs;
   *bucket0_floats = P->gs_bucket0;
-  *total_floats = (int64_t)(P->gs_floats - P->stats_floats * NUNET_BN_SUM_REPLICAS);
+  *total_floats = (int64_t)P->gs_floats;
   return NUNET_OK;
 }
 
@@ -1280,7 +1140,7 @@ extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, 
   return nunet_check_launch("plan_update");
 }
 
-// Optimiser step straight from the gradient scratch (unpack_sgd_kernel): replaces nunet_plan_backward_phase bit 2 +
+// Optimiser step straight from the gradient scratch: replaces nunet_plan_backward_phase bit 2 +
 // nunet_sgd_step; the weights are repacked by the next nunet_plan_forward as usual.
 // unpack_tiled_kernel with the optimiser step as the epilogue of its store phase: the tile's gradients meet the OIHW
 // parameters and momentum as 16-byte runs, the flat gradient arena is written only when the caller wants it.
@@ -1381,20 +1241,12 @@ extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, voi
   UpdP u;
   u.params = params; u.mom = momentum; u.scratch = (const float*)AB(arena, P->off_gs); u.grads = grads; u.lr = lr_dev;
   u.momc = mom; u.wd = wd; u.gscale = grad_scale; u.nesterov = nesterov; u.nconv = P->ptab.n;
-  int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
-  if (gx > 512) gx = 512;
   ProfScope ps(PC_SGD, 0, (double)P->nparams * (grads ? 24.0 : 20.0), st);
-  static int tiled = -1;
-  if (tiled < 0) { const char* e = getenv("NUNET_UNPACK_TILED"); tiled = e ? atoi(e) : 1; }
-  if (tiled) {
-    PackTab& tab = P->ptab;
-    int nt = 0;
-    for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
-    tab.tile0[tab.n] = nt; tab.ntiles = nt;
-    hipLaunchKernelGGL(unpack_sgd_tiled_kernel, dim3(nt + P->utab.n), dim3(256), 0, st, u, tab, P->utab);
-  } else {
-    hipLaunchKernelGGL(unpack_sgd_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, u, P->utab);
-  }
+  PackTab& tab = P->ptab;
+  int nt = 0;
+  for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
+  tab.tile0[tab.n] = nt; tab.ntiles = nt;
+  hipLaunchKernelGGL(unpack_sgd_tiled_kernel, dim3(nt + P->utab.n), dim3(256), 0, st, u, tab, P->utab);
   return nunet_check_launch("plan_sgd");
 }
 
@@ -1409,7 +1261,57 @@ extern "C" int nunet_plan_repack(nunet_plan* P, const float* params, void* arena
   return launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, (hipStream_t)s);
 }
 
-// phases: 1 = clear scratch, heads and the last anti-diagonal's blocks (75 % of the gradient bytes);
+// Sum of the weight gradients' K-split slabs into the native-layout gradient scratch, all layers of a phase in one
+// launch. A block owns 64 float4 outputs of one layer; thread (part, e) adds slabs part, part + 4, ... in order, the
+// four parts meet in LDS in order: a fixed summation tree, so the gradient is bit-identical from run to run.
+#define MAXRED 40
+struct RedEnt { long long slab, dst, stride, n4; int ks, blk0; };
+struct RedTab { int n, nblocks; RedEnt e[MAXRED]; };
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gs, RedTab tab) {
+  __shared__ f32x4 s_p[4][64];
+  int e = 0;
+  while (e + 1 < tab.n && (int)blockIdx.x >= tab.e[e + 1].blk0) ++e;
+  const RedEnt en = tab.e[e];
+  const int part = threadIdx.x >> 6, el = threadIdx.x & 63;
+  const long long i = ((long long)blockIdx.x - en.blk0) * 64 + el;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < en.n4) {
+    const float* q = slabs + en.slab + i * 4;
+#pragma unroll 4
+    for (int sl = part; sl < en.ks; sl += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(q + (size_t)sl * en.stride);
+      a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+  }
+  s_p[part][el] = a;
+  __syncthreads();
+  if (part == 0 && i < en.n4) {
+    f32x4 r = s_p[0][el];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) { const f32x4 v = s_p[q][el]; r[0] += v[0]; r[1] += v[1]; r[2] += v[2]; r[3] += v[3]; }
+    *reinterpret_cast<f32x4*>(gs + en.dst + i * 4) = r;
+  }
+}
+// layers of exec nodes [k_lo, k_hi] whose gradient was split (ks > 1; unsplit layers write the scratch directly)
+static int launch_reduce(nunet_plan* P, void* arena, int k_lo, int k_hi, hipStream_t st) {
+  RedTab tab; tab.n = 0; tab.nblocks = 0;
+  double bytes = 0;
+  for (int k = k_hi; k >= k_lo; --k)
+    for (int cv = 1; cv >= 0; --cv) {
+      const ConvL& c = cv ? P->exec[k].c2 : P->exec[k].c1;
+      if (c.ks <= 1) continue;
+      RedEnt& en = tab.e[tab.n++];
+      en.slab = c.slab; en.dst = c.gs; en.stride = 9LL * c.cout * c.cinpad; en.n4 = en.stride / 4; en.ks = c.ks; en.blk0 = tab.nblocks;
+      tab.nblocks += (int)((en.n4 + 63) / 64);
+      bytes += (double)en.stride * 4 * (c.ks + 1);
+    }
+  if (tab.n == 0) return NUNET_OK;
+  ProfScope ps(PC_UNPACK, 0, bytes, st);
+  hipLaunchKernelGGL(reduce_kernel, dim3(tab.nblocks), dim3(256), 0, st, (const float*)AB(arena, P->off_slab), (float*)AB(arena, P->off_gs), tab);
+  return nunet_check_launch("wgrad slab reduce");
+}
+
+// phases: 1 = heads and the last anti-diagonal's blocks (75 % of the gradient bytes);
 //         2 = the remaining blocks; 4 = unpack into the flat OIHW gradient arena. 7 = everything.
 extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s) {
   NUNET_REQUIRE(P && params && dlogits && arena && grads, "plan_backward: null pointer");
@@ -1417,17 +1319,11 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   const nunet_plan_cfg& c = P->cfg;
   const int dt = c.dtype, es = P->es;
   float* gsr = (float*)AB(arena, P->off_gs);
-  float* bsums = gsr + (P->gs_floats - P->stats_floats * NUNET_BN_SUM_REPLICAS);
+  float* slabs = (float*)AB(arena, P->off_slab);
   float* save = (float*)AB(arena, P->off_save);
   char* wpack = AB(arena, P->off_wpack);
   bool (&written)[5][5] = rt_of(P)->bwd_written;
-  int (&pp)[5] = rt_of(P)->bwd_pp;   // per-level ping-pong of the dY scratch
-  if (phases & 1) {
-    if (rt_of(P)->gs_clean_arena == arena) rt_of(P)->gs_clean_arena = nullptr;   // cleared by the forward that produced the activations
-    else CK(nunet_zero_async(gsr, P->gs_floats * 4, st));
-    memset(written, 0, sizeof(written));
-    memset(pp, 0, sizeof(pp));
-  }
+  if (phases & 1) memset(written, 0, sizeof(written));
   const int nnodes = (int)P->exec.size();
   const int k_split = nnodes - P->first_phase_nodes;      // phase 1: nodes [k_split, nnodes); phase 2: [0, k_split)
   const int k_hi = (phases & 1) ? nnodes - 1 : k_split - 1;
@@ -1436,27 +1332,18 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   Sched S; S.init(P, st, 1);
   int rc = NUNET_OK;
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
-  // cost model (us) of the simulated schedule: launch floor + algorithmic work at the rate these
-  // kernels reach on MI355X (profiles/r01_summary.md); only the relative order matters
-  const double conv_rate = dt == NUNET_F32 ? 0.09e9 : 0.55e9, wg_rate = dt == NUNET_F32 ? 0.07e9 : 0.40e9;   // FLOP per us
-  auto cost_conv = [&](int lvl, double cin, double cout) { return (float)(9.0 + (lvl >= 3 ? 8.0 : 0.0) + 18.0 * cin * cout * (double)P->px[lvl] / conv_rate); };
-  auto cost_wg = [&](int lvl, double cin, double cout) { return (float)(12.0 + 18.0 * cin * cout * (double)P->px[lvl] / wg_rate); };
-  auto cost_mem = [&](double floor_us, double bytes) { return (float)(floor_us + bytes / 4.0e6); };
-  static int bnr_fuse_env = -1;
-  // measured: fusing takes 1 % off the summed kernel time but the step gets 0.5 % slower (schedule): off by default
-  if (bnr_fuse_env < 0) { const char* e = getenv("NUNET_BNR_FUSE"); bnr_fuse_env = e ? atoi(e) : 0; }
-  const bool bnr_fuse = bnr_fuse_env != 0;
   for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK && (phases & 1); ++k) {
     const Head& h = P->heads[k];
     const int acc = written[0][h.slot] ? 1 : 0;
     S.name("head%d.B", (int)k);
-    S.add(0, 0, 12.f, {R_X + h.slot, R_DLOGITS}, {R_GX + h.slot, R_GSV + 30 + (int)k}, [=](hipStream_t ls) {
+    S.add(0, 0, 0.f, {R_X + h.slot, R_DLOGITS}, {R_GX + h.slot, R_GSV + 30 + (int)k}, [=](hipStream_t ls) {
       return nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
                             params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
                             acc, gsr + h.gs, HEAD_SLABS, ls);
     });
     written[0][h.slot] = true;
   }
+  const bool b0_inside = (phases & 3) == 3 && rt_of(P)->b0_enabled && !P->cfg.unet;   // bucket 0 signalled from inside the pass
 
   for (int k = k_hi; k >= k_lo && rc == NUNET_OK; --k) {
     const Node& n = P->exec[k];
@@ -1464,125 +1351,123 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     const int lane = lane_of(P, n), wlane = 5 + lane, rb = R_BLK + k * B_STRIDE, rl = R_LVL + k * L_STRIDE;
     const int rsk = P->sk_floats[i] > 0 ? R_SK + i : -1;
     if (!written[i][n.out_slot]) { nunet_set_error("plan_backward: internal: grad of x%d_%d never produced", n.i, n.j); rc = NUNET_EINVAL; break; }
-    nunet_wgrad_desc wdesc[2]; int wrdy[2] = {-1, -1};
-    for (int cv = 1; cv >= 0 && rc == NUNET_OK; --cv) {
-      const ConvL& L = cv == 0 ? n.c1 : n.c2;
-      const int cidx = 2 * k + cv;
-      const int rdy = rl + (pp[i] ? L_DY1 : L_DY0);
-      char* dybuf = AB(arena, P->off_dy[k][pp[i]]);
-      pp[i] ^= 1;
-      // BN + ReLU backward
-      nunet_bn_bwd_desc b; memset(&b, 0, sizeof(b));
-      b.dtype = dt; b.N = c.N; b.H = H; b.W = W; b.C = f;
-      int rda, ry;
-      if (cv == 1) { b.da = AB(arena, P->GX[i] + (size_t)n.out_slot * f * es); b.PDA = P->PX[i]; b.y = AB(arena, n.y2); rda = R_GX + i * 5 + n.out_slot; ry = rb + B_Y2; }
-      else { b.da = AB(arena, P->off_da1[k]); b.PDA = f; b.y = AB(arena, n.y1); rda = rl + L_DA1; ry = rb + B_Y1; }
-      b.PY = f; b.mean_invstd = save + L.save; b.gamma = params + L.g_off; b.beta = params + L.be_off;
-      b.sums = bsums + L.bsum * NUNET_BN_SUM_REPLICAS;
-      float* gl = gsr + L.gs + 9LL * L.cout * L.cinpad;
-      b.dbias = gl; b.dgamma = gl + L.cout; b.dbeta = gl + 2 * L.cout;
-      b.dy = dybuf; b.PDY = f;
-      S.name("B%d%d.bnB%d", n.i, n.j, cv + 1);
-      // the reduce pass of the FIRST conv's BN is taken in the epilogue of the dgrad that produces its
-      // input gradient (conv3x3 BNR kernels): one launch and one read of da1 and y1 less per block
-      const bool fused_reduce = bnr_fuse && cv == 0;
-      S.add(lane, 0, cost_mem(fused_reduce ? 6.0 : 12.0, (fused_reduce ? 3.0 : 5.0) * (double)P->px[i] * f * es), {rda, ry}, {rdy, R_GSV + cidx}, [=](hipStream_t ls) {
-        int r = fused_reduce ? NUNET_OK : nunet_bn_relu_bwd_reduce(&b, ls);
-        return r ? r : nunet_bn_relu_bwd_apply(&b, ls);
-      });
-      // weight gradient: a leaf of the dependency graph (only the final unpack reads it)
-      nunet_wgrad_desc& w = wdesc[cv]; memset(&w, 0, sizeof(w));
-      w.dtype = dt; w.N = c.N; w.H = H; w.W = W;
-      if (cv == 1) { w.src0 = AB(arena, n.a1); w.C0 = f; w.P0 = f; }
-      else if (n.in_prefix == 0) {
-        if (i == 0) { w.src0 = AB(arena, P->off_img); w.C0 = 32; w.P0 = 32; }
-        else { w.src0 = AB(arena, n.pin); w.C0 = NBF[i - 1]; w.P0 = NBF[i - 1]; }
-      } else {
-        w.src0 = AB(arena, P->X[i]); w.C0 = n.in_prefix * f; w.P0 = P->PX[i];
-        w.src1 = AB(arena, n.up); w.C1 = NBF[i + 1]; w.P1 = NBF[i + 1];
-      }
-      w.dy = b.dy; w.Cout = f; w.PY = f; w.dw = gsr + L.gs;
-      wrdy[cv] = rdy;
-      // dgrad
-      if (cv == 0 && i == 0 && n.in_prefix == 0) continue;  // no gradient into the image
+    const ConvL& L1 = n.c1; const ConvL& L2 = n.c2;
+    char* const dy2 = AB(arena, P->off_dy[k][0]); char* const dy1 = AB(arena, P->off_dy[k][1]);
+    char* const da1 = AB(arena, P->off_da1[k]);
+    const int r_dy2 = rl + L_DY0, r_dy1 = rl + L_DY1, r_da1 = rl + L_DA1;
+    const int r_v2 = R_GSV + 2 * k + 1, r_v1 = R_GSV + 2 * k;       // per-conv sums + small-vector gradients
+    const int r_gxo = R_GX + i * 5 + n.out_slot;
+    float* const gv2 = gsr + L2.gs + 9LL * L2.cout * L2.cinpad;     // [dbias | dgamma | dbeta]
+    float* const gv1 = gsr + L1.gs + 9LL * L1.cout * L1.cinpad;
+    const bool has_dgrad1 = !(i == 0 && n.in_prefix == 0);           // no gradient into the image
+
+    // ---- BatchNorm2 + ReLU backward, REDUCE pass: sum dz, sum dz * xhat over the block-output gradient (which several
+    // consumers accumulated into its level-buffer slot) -> fixed-point sums
+    nunet_bn_bwd_desc b2; memset(&b2, 0, sizeof(b2));
+    b2.dtype = dt; b2.N = c.N; b2.H = H; b2.W = W; b2.C = f;
+    b2.da = AB(arena, P->GX[i] + (size_t)n.out_slot * f * es); b2.PDA = P->PX[i]; b2.y = AB(arena, n.y2); b2.PY = f;
+    b2.mean_invstd = save + L2.save; b2.gamma = params + L2.g_off; b2.beta = params + L2.be_off;
+    b2.sums = (int64_t*)fx_of(arena, P, 1, L2.bsum);
+    S.name("B%d%d.bnR2", n.i, n.j);
+    S.add(lane, 0, 0.f, {r_gxo, rb + B_Y2}, {r_v2}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_reduce(&b2, ls); });
+
+    // ---- dgrad of conv2: the APPLY pass of BatchNorm2's backward happens on the way into LDS (dy2 is stored on the
+    // side for the weight gradient); the epilogue takes BatchNorm1's reduce pass on the da1 it stores (archs1.py:23-30)
+    {
       nunet_conv_desc d; memset(&d, 0, sizeof(d));
       d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
-      d.src0 = b.dy; d.C0 = f; d.P0 = f;
-      d.wpack = wpack + (size_t)L.wd * es;
+      d.src0 = b2.da; d.C0 = f; d.P0 = P->PX[i];
+      d.in_tf = NUNET_TF_BN_RELU_BWD; d.tf_y = AB(arena, n.y2); d.tf_py = f; d.tf_fx = b2.sums;
+      d.tf_gamma = b2.gamma; d.tf_beta = b2.beta; d.tf_mean_invstd = save + L2.save;
+      d.tf_dbias = gv2; d.tf_dgamma = gv2 + L2.cout; d.tf_dbeta = gv2 + 2 * L2.cout;
+      d.tf_store = dy2; d.tf_ps = f;
+      d.wpack = wpack + (size_t)L2.wd * es;
+      d.dst0 = da1; d.D0 = f; d.Q0 = f;
+      d.bn_y = AB(arena, n.y1); d.bn_py = f; d.bn_mean_invstd = save + L1.save;
+      d.bn_gamma = params + L1.g_off; d.bn_beta = params + L1.be_off; d.bn_sums = (int64_t*)fx_of(arena, P, 1, L1.bsum);
       if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
-      S.name("B%d%d.dgrad%d", n.i, n.j, cv + 1);
-      if (cv == 1) {
-        d.dst0 = AB(arena, P->off_da1[k]); d.D0 = f; d.Q0 = f;
-        if (bnr_fuse) {
-          const ConvL& L1 = n.c1;
-          d.bn_y = AB(arena, n.y1); d.bn_py = f; d.bn_mean_invstd = save + L1.save;
-          d.bn_gamma = params + L1.g_off; d.bn_beta = params + L1.be_off; d.bn_sums = bsums + L1.bsum * NUNET_BN_SUM_REPLICAS;
-        }
-        S.add(lane, 0, cost_conv(i, f, f), {rdy, bnr_fuse ? rb + B_Y1 : -1}, {rl + L_DA1, rsk, bnr_fuse ? R_GSV + 2 * k : -1}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
-      } else if (n.in_prefix == 0) {
+      S.name("B%d%d.dgrad2", n.i, n.j);
+      S.add(lane, 0, 0.f, {r_gxo, rb + B_Y2, rb + B_Y1, R_WP + i}, {r_dy2, r_da1, r_v2, r_v1, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
+    }
+    // ---- dgrad of conv1 with BatchNorm1's apply pass on the way in; the first block has no input gradient and
+    // runs the stand-alone apply pass for its weight gradient instead
+    if (has_dgrad1) {
+      nunet_conv_desc d; memset(&d, 0, sizeof(d));
+      d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
+      d.src0 = da1; d.C0 = f; d.P0 = f;
+      d.in_tf = NUNET_TF_BN_RELU_BWD; d.tf_y = AB(arena, n.y1); d.tf_py = f; d.tf_fx = (const int64_t*)fx_of(arena, P, 1, L1.bsum);
+      d.tf_gamma = params + L1.g_off; d.tf_beta = params + L1.be_off; d.tf_mean_invstd = save + L1.save;
+      d.tf_dbias = gv1; d.tf_dgamma = gv1 + L1.cout; d.tf_dbeta = gv1 + 2 * L1.cout;
+      d.tf_store = dy1; d.tf_ps = f;
+      d.wpack = wpack + (size_t)L1.wd * es;
+      if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
+      S.name("B%d%d.dgrad1", n.i, n.j);
+      if (n.in_prefix == 0) {
         d.dst0 = AB(arena, P->off_gpin[k]); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1];
-        S.add(lane, 0, cost_conv(i, f, NBF[i - 1]) + (i >= 3 ? 12.f : 0.f), {rdy}, {rl + L_GPIN, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
+        S.add(lane, 0, 0.f, {r_da1, rb + B_Y1, r_v1, R_WP + i}, {r_dy1, rl + L_GPIN, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
+        // through MaxPool2d(2,2) into x_{i-1,0}
+        const int acc = written[i - 1][0] ? 1 : 0;
+        S.name("B%d%d.poolB", n.i, n.j);
+        S.add(lane, 0, 0.f, {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0}, [=](hipStream_t ls) {
+          return nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
+                                      AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], acc, ls);
+        });
+        written[i - 1][0] = true;
       } else {
         d.dst0 = AB(arena, P->GX[i]); d.D0 = n.in_prefix * f; d.Q0 = P->PX[i]; d.acc_slot_w = f;
         for (int q = 0; q < n.in_prefix; ++q) { if (written[i][q]) d.acc0_mask |= 1u << q; written[i][q] = true; }
         d.dst1 = AB(arena, P->off_gup[k]); d.D1 = NBF[i + 1]; d.Q1 = NBF[i + 1];
-        S.add(lane, 0, cost_conv(i, f, n.in_prefix * f + NBF[i + 1]), {rdy},
-              {R_GX + i * 5 + 0, n.in_prefix > 1 ? R_GX + i * 5 + 1 : -1, n.in_prefix > 2 ? R_GX + i * 5 + 2 : -1,
+        S.add(lane, 0, 0.f, {r_da1, rb + B_Y1, r_v1, R_WP + i},
+              {r_dy1, R_GX + i * 5 + 0, n.in_prefix > 1 ? R_GX + i * 5 + 1 : -1, n.in_prefix > 2 ? R_GX + i * 5 + 2 : -1,
                n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
+        // through the bilinear upsample into x_{i+1,up_slot}
+        const int acc = written[i + 1][n.up_slot] ? 1 : 0;
+        S.name("B%d%d.upB", n.i, n.j);
+        S.add(lane, 0, 0.f, {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot}, [=](hipStream_t ls) {
+          return nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
+                                      AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], acc, ls);
+        });
+        written[i + 1][n.up_slot] = true;
       }
-      if (cv == 0) {
-        if (n.in_prefix == 0) {
-          // through MaxPool2d(2,2) into x_{i-1,0}
-          const int acc = written[i - 1][0] ? 1 : 0;
-          S.name("B%d%d.poolB", n.i, n.j);
-          S.add(lane, 0, cost_mem(5.0, 2.5 * (double)P->px[i - 1] * NBF[i - 1] * es), {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0}, [=](hipStream_t ls) {
-            return nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
-                                        AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], acc, ls);
-          });
-          written[i - 1][0] = true;
-        } else {
-          // through the bilinear upsample into x_{i+1,up_slot}
-          const int acc = written[i + 1][n.up_slot] ? 1 : 0;
-          S.name("B%d%d.upB", n.i, n.j);
-          S.add(lane, 0, cost_mem(8.0, 1.5 * (double)P->px[i] * NBF[i + 1] * es), {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot}, [=](hipStream_t ls) {
-            return nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
-                                        AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], acc, ls);
-          });
-          written[i + 1][n.up_slot] = true;
-        }
-      }
+    } else {
+      nunet_bn_bwd_desc b1; memset(&b1, 0, sizeof(b1));
+      b1.dtype = dt; b1.N = c.N; b1.H = H; b1.W = W; b1.C = f;
+      b1.da = da1; b1.PDA = f; b1.y = AB(arena, n.y1); b1.PY = f;
+      b1.mean_invstd = save + L1.save; b1.gamma = params + L1.g_off; b1.beta = params + L1.be_off;
+      b1.sums = (int64_t*)fx_of(arena, P, 1, L1.bsum);
+      b1.dbias = gv1; b1.dgamma = gv1 + L1.cout; b1.dbeta = gv1 + 2 * L1.cout;
+      b1.dy = dy1; b1.PDY = f;
+      S.name("B%d%d.bnA1", n.i, n.j);
+      S.add(lane, 0, 0.f, {r_da1, rb + B_Y1, r_v1}, {r_dy1}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_apply(&b1, ls); });
     }
-    static int wg_pair = -1;
-    if (wg_pair < 0) { const char* e = getenv("NUNET_WGRAD_PAIR"); wg_pair = e ? atoi(e) : 1; }
-    if (wg_pair && rc == NUNET_OK) {
-      // both weight gradients of the block in one launch (conv1's problem first: it may carry the
-      // first layer's algorithmic Cin for the profiler)
-      const nunet_wgrad_desc w0 = wdesc[0], w1 = wdesc[1];
+    // ---- both weight gradients of the block in one launch (leaves of the dependency graph: only the slab reduce
+    // reads them); conv1's problem first: it may carry the first layer's algorithmic Cin for the profiler
+    {
+      nunet_wgrad_desc w1, w2; memset(&w1, 0, sizeof(w1)); memset(&w2, 0, sizeof(w2));
+      w1.dtype = w2.dtype = dt; w1.N = w2.N = c.N; w1.H = w2.H = H; w1.W = w2.W = W;
+      w2.src0 = AB(arena, n.a1); w2.C0 = f; w2.P0 = f;
+      if (n.in_prefix == 0) {
+        if (i == 0) { w1.src0 = AB(arena, P->off_img); w1.C0 = 32; w1.P0 = 32; }
+        else { w1.src0 = AB(arena, n.pin); w1.C0 = NBF[i - 1]; w1.P0 = NBF[i - 1]; }
+      } else {
+        w1.src0 = AB(arena, P->X[i]); w1.C0 = n.in_prefix * f; w1.P0 = P->PX[i];
+        w1.src1 = AB(arena, n.up); w1.C1 = NBF[i + 1]; w1.P1 = NBF[i + 1];
+      }
+      w1.dy = dy1; w2.dy = dy2; w1.Cout = w2.Cout = f; w1.PY = w2.PY = f;
+      w1.dw = L1.ks > 1 ? slabs + L1.slab : gsr + L1.gs; w1.slab_stride = 9LL * L1.cout * L1.cinpad; w1.max_slabs = L1.ks; w1.target_wgs = L1.wg_target;
+      w2.dw = L2.ks > 1 ? slabs + L2.slab : gsr + L2.gs; w2.slab_stride = 9LL * L2.cout * L2.cinpad; w2.max_slabs = L2.ks; w2.target_wgs = L2.wg_target;
       const int alg_cin = (i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
-      const float cw = cost_wg(i, (double)w0.C0 + w0.C1, f) + cost_wg(i, (double)w1.C0 + w1.C1, f) - 8.f;
       S.name("B%d%d.wgrad", n.i, n.j);
       int rx[4] = {-1, -1, -1, -1}, r_in = -1, r_up = -1;
       if (n.in_prefix == 0) r_in = (i == 0 ? R_IMG : rb + B_PIN);
       else { for (int q = 0; q < n.in_prefix && q < 4; ++q) rx[q] = R_X + i * 5 + q; r_up = rb + B_UP; }
-      S.add(wlane, 1, cw, {rb + B_A1, wrdy[1], wrdy[0], r_in, rx[0], rx[1], rx[2], rx[3], r_up}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
-            [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w0, &w1, ls); g_prof_alg_cin = 0; return r; });
+      S.add(wlane, 1, 0.f, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
+            [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w1, &w2, ls); g_prof_alg_cin = 0; return r; });
     }
-    for (int cv = 1; cv >= 0 && rc == NUNET_OK && !wg_pair; --cv) {
-      const int cidx = 2 * k + cv;
-      const nunet_wgrad_desc w = wdesc[cv];
-      const int alg_cin = (cv == 0 && i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
-      auto fn = [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad(&w, ls); g_prof_alg_cin = 0; return r; };
-      const float cw = cost_wg(i, (double)w.C0 + w.C1, f);
-      S.name("B%d%d.wgrad%d", n.i, n.j, cv + 1);
-      if (cv == 1) S.add(wlane, 1, cw, {rb + B_A1, wrdy[cv]}, {R_GSW + cidx}, fn);
-      else if (n.in_prefix == 0) S.add(wlane, 1, cw, {i == 0 ? R_IMG : rb + B_PIN, wrdy[cv]}, {R_GSW + cidx}, fn);
-      else S.add(wlane, 1, cw, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
-                                n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, wrdy[cv]}, {R_GSW + cidx}, fn);
-    }
-    // "bucket 0 complete" (data-parallel exchange beside the rest of the backward pass, nunet_plan_bucket0_*): an empty op
-    // on the otherwise unused lane 4 that reads every gradient resource of the phase-1 nodes and the heads, then records
-    // the plan's event there - as an external event record node when the pass is being captured into a graph
-    if (k == k_split && (phases & 3) == 3 && rt_of(P)->b0_enabled && !P->cfg.unet && S.multi) {
+    // "bucket 0 complete" (data-parallel exchange beside the rest of the backward pass, nunet_plan_bucket0_*): on the otherwise
+    // unused lane 4, ops that read every gradient resource of the phase-1 nodes and the heads; the last one sums the phase's
+    // weight-gradient slabs and records the plan's event - as an external event record node when the pass is being captured
+    if (k == k_split && b0_inside && S.multi) {
       std::vector<int> rs;
       for (int kk = k_split; kk < nnodes; ++kk) { rs.push_back(R_GSW + 2 * kk); rs.push_back(R_GSW + 2 * kk + 1); rs.push_back(R_GSV + 2 * kk); rs.push_back(R_GSV + 2 * kk + 1); }
       for (size_t h = 0; h < P->heads.size(); ++h) rs.push_back(R_GSV + 30 + (int)h);
@@ -1592,6 +1477,8 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
         S.name("b0rdy");
         S.add_v(4, 1, 0.f, rs.data() + q, (int)std::min<size_t>(10, rs.size() - q), [=](hipStream_t ls) {
           if (!last) return (int)NUNET_OK;
+          int r = launch_reduce(P, arena, k_split, nnodes - 1, ls);
+          if (r) return r;
           hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
           (void)hipStreamIsCapturing(ls, &cs);
           if (cs == hipStreamCaptureStatusActive) return graph_record_external(ls, ev);
@@ -1604,23 +1491,21 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   }
   if (rc == NUNET_OK) rc = S.run_ops();
   S.join();
-  if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_backward: capture lane pool exhausted"); rc = NUNET_EINVAL; }
+  if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_backward: lane scheduler overflow (capture stream pool / dependency lists)"); rc = NUNET_EINVAL; }
   if (rc) return rc;
+  // slab sums of the nodes this call covered (phase-1 nodes were already reduced inside the pass when bucket 0 is signalled there)
+  if (phases & 3) {
+    const int lo = k_lo, hi = (b0_inside && S.multi) ? k_split - 1 : k_hi;
+    if (hi >= lo) CK(launch_reduce(P, arena, lo, hi, st));
+  }
   if (!(phases & 4)) return NUNET_OK;
   P->utab.accumulate = accumulate;
-  int gx = (int)ceil_div64(P->unpack_maxn, 256 * 4);
-  if (gx > 512) gx = 512;
   ProfScope ps(PC_UNPACK, 0, (double)P->nparams * (accumulate ? 12 : 8), st);
-  static int tiled = -1;
-  if (tiled < 0) { const char* e = getenv("NUNET_UNPACK_TILED"); tiled = e ? atoi(e) : 1; }
-  if (tiled) {
-    PackTab& tab = P->ptab;
-    int nt = 0;
-    for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
-    tab.tile0[tab.n] = nt; tab.ntiles = nt;
-  }
-  if (tiled) hipLaunchKernelGGL(unpack_tiled_kernel, dim3(P->ptab.ntiles + P->utab.n), dim3(256), 0, st, gsr, grads, P->ptab, P->utab);
-  else hipLaunchKernelGGL(unpack_kernel, dim3(gx, P->utab.n), dim3(256), 0, st, gsr, grads, P->utab);
+  PackTab& tab = P->ptab;
+  int nt = 0;
+  for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
+  tab.tile0[tab.n] = nt; tab.ntiles = nt;
+  hipLaunchKernelGGL(unpack_tiled_kernel, dim3(P->ptab.ntiles + P->utab.n), dim3(256), 0, st, gsr, grads, P->ptab, P->utab);
   return nunet_check_launch("unpack_grads");
 }
 

@@ -55,6 +55,22 @@ def synth_batch(n, h, w, cin=3, ncls=1, seed=1234):
     return synth_images(n, h, w, cin, seed), synth_masks(n, h, w, ncls, seed)
 
 
+def synth_blob_pairs(n, h, w, seed=1234, cin=3):
+    """A LEARNABLE segmentation set (the "val IoU vs ref" fixture): the image is rendered from
+    the blob mask - background pixels U{0..199}, nuclei pixels U{56..255} per channel, so a single pixel says
+    little (72 % of either range is shared) and the network needs spatial context - then goes through the same uint8 -> Normalize -> /255
+    pipeline as synth_images (reference dataset.py:66-74). Returns (image [n,cin,h,w] f32, mask [n,1,h,w] f32)."""
+    msk = synth_masks(n, h, w, 1, seed)
+    rng = np.random.default_rng(seed + 104729)
+    bg = rng.integers(0, 200, size=(n, h, w, cin), dtype=np.int32)
+    fg = rng.integers(56, 256, size=(n, h, w, cin), dtype=np.int32)
+    raw = np.where(msk[:, 0, :, :, None] > 0.5, fg, bg).astype(np.uint8).astype(np.float64)
+    mean = np.resize(_MEAN, cin)
+    std = np.resize(_STD, cin)
+    x = ((raw / 255.0 - mean) / std) / 255.0
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32), msk
+
+
 # ---------------------------------------------------------------------------
 # model topology (reference finished/archs1.py:85-111,113-143)
 # ---------------------------------------------------------------------------
@@ -150,6 +166,54 @@ def closed_form_state(ncls=1, cin=3, deep_supervision=False, fresh_bn=True, salt
             v = np.ones(n) if fresh_bn else 0.02 + 0.05 * (u + 1.0)
         elif kind == "bn_nbt":
             out[name] = np.array(0 if fresh_bn else 3, dtype=np.int64)
+            continue
+        out[name] = v.reshape(shape).astype(np.float32)
+    return out
+
+
+def unet_state_dict_spec(ncls=1, cin=3):
+    """Ordered [(name, shape, kind)] of the reference plain U-Net's state_dict (reference finished/archs1.py:35-71):
+    encoder column conv{i}_0, then decoder conv3_1, conv2_2, conv1_3, conv0_4, then `final`."""
+    f = NB_FILTER
+    blocks = [("conv%d_0" % i, (cin if i == 0 else f[i - 1]), f[i]) for i in range(5)]
+    blocks += [("conv%d_%d" % (i, 4 - i), f[i] + f[i + 1], f[i]) for i in (3, 2, 1, 0)]
+    spec = []
+    for name, ci, co in blocks:
+        for k, (a, b) in (("1", (ci, co)), ("2", (co, co))):
+            spec.append((name + ".conv%s.weight" % k, (b, a, 3, 3), "conv_w"))
+            spec.append((name + ".conv%s.bias" % k, (b,), "conv_b"))
+            spec.append((name + ".bn%s.weight" % k, (b,), "bn_w"))
+            spec.append((name + ".bn%s.bias" % k, (b,), "bn_b"))
+            spec.append((name + ".bn%s.running_mean" % k, (b,), "bn_rm"))
+            spec.append((name + ".bn%s.running_var" % k, (b,), "bn_rv"))
+            spec.append((name + ".bn%s.num_batches_tracked" % k, (), "bn_nbt"))
+    spec.append(("final.weight", (ncls, f[0], 1, 1), "conv_w"))
+    spec.append(("final.bias", (ncls,), "conv_b"))
+    return spec
+
+
+def closed_form_state_unet(ncls=1, cin=3):
+    """closed_form_state() for the plain U-Net (fresh BatchNorm buffers), hash streams 5000+."""
+    out = {}
+    fan_in = 1
+    for t, (name, shape, kind) in enumerate(unet_state_dict_spec(ncls, cin)):
+        n = int(np.prod(shape)) if len(shape) else 1
+        u = _hash_uniform(n, 5000 + t)
+        if kind == "conv_w":
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = u / math.sqrt(fan_in)
+        elif kind == "conv_b":
+            v = u / math.sqrt(fan_in)
+        elif kind == "bn_w":
+            v = 1.0 + 0.1 * u
+        elif kind == "bn_b":
+            v = 0.1 * u
+        elif kind == "bn_rm":
+            v = np.zeros(n)
+        elif kind == "bn_rv":
+            v = np.ones(n)
+        else:
+            out[name] = np.array(0, dtype=np.int64)
             continue
         out[name] = v.reshape(shape).astype(np.float32)
     return out

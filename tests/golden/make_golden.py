@@ -120,6 +120,45 @@ def run_case(name, cfg):
     print(name, "loss", float(out["loss"]), "iou", float(out["iou"]))
 
 
+def run_unet():
+    """Plain U-Net (reference finished/archs1.py:35-71): one training-mode forward/backward on closed-form weights."""
+    n, h, w, cin, ncls = 2, 32, 32, 3, 1
+    torch.manual_seed(0)
+    model = ref_archs.UNet(ncls, cin)
+    st = synth.closed_form_state_unet(ncls, cin)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(st.keys()), "unet_state_dict_spec drifted from the reference"
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
+    crit = ref_losses.BCEDiceLoss()
+    img, msk = synth.synth_batch(n, h, w, cin, ncls, seed=1234)
+    x, t = torch.from_numpy(img), torch.from_numpy(msk)
+    model.train()
+    o = model(x)
+    loss = crit(o, t)
+    iou = ref_metrics.iou_score(o, t)
+    model.zero_grad()
+    loss.backward()
+    out = {"logits0": o.detach().numpy(), "loss": np.float64(loss.item()), "iou": np.float64(iou)}
+    names, l2s, samples = [], [], []
+    for k, p in model.named_parameters():
+        s = summarize(p.grad)
+        names.append(k); l2s.append(s["l2"])
+        smp = np.zeros(64, np.float32); smp[:s["sample"].size] = s["sample"]
+        samples.append(smp)
+        if p.numel() <= 2048:
+            out["grad/" + k] = p.grad.detach().numpy()
+    out["grad_names"] = np.array(names); out["grad_l2"] = np.array(l2s); out["grad_sample"] = np.stack(samples)
+    bn = {k: v for k, v in model.state_dict().items() if "running_" in k}
+    out["bn_names"] = np.array(list(bn.keys()))
+    out["bn_sum"] = np.array([float(v.double().sum()) for v in bn.values()])
+    np.savez_compressed(os.path.join(HERE, "h_unet_n2_32x32_k1.npz"), **out)
+    print("unet loss", float(out["loss"]), "iou", float(out["iou"]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "unet":
+    run_unet()
+
+
 def run_trajectory():
     """K steps of the reference loop body (trains.py:113-135) with SGD defaults
     (trains.py:73-85,229-231) and CosineAnnealingLR stepped per 'epoch'
@@ -199,9 +238,10 @@ if __name__ == "__main__" and len(sys.argv) == 1:
         run_case(name, cfg)
     run_trajectory()
     run_small_ops()
+    run_unet()
 
 
-def run_training_log(epochs=6, train_size=256, val_size=64, bs=16, hw=96, lr=1e-2):
+def run_training_log(epochs=30, train_size=512, val_size=128, bs=16, hw=96, lr=1e-2):
     """'val IoU vs ref' in its offline-feasible form: the REFERENCE model/loss/metric
     trained here with torch.optim.SGD + CosineAnnealingLR (trains.py:229-239) on the seeded synthetic
     blob set, the same shuffle stream as train.py. Commits the per-epoch log as a fixture."""
@@ -210,8 +250,8 @@ def run_training_log(epochs=6, train_size=256, val_size=64, bs=16, hw=96, lr=1e-
     crit = ref_losses.BCEDiceLoss()
     opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, nesterov=False, weight_decay=1e-4)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=epochs, eta_min=1e-5)
-    img, msk = synth.synth_batch(train_size, hw, hw, 3, 1, seed=1000)
-    vimg, vmsk = synth.synth_batch(val_size, hw, hw, 3, 1, seed=2000)
+    img, msk = synth.synth_blob_pairs(train_size, hw, hw, seed=1000)
+    vimg, vmsk = synth.synth_blob_pairs(val_size, hw, hw, seed=2000)
     x, t = torch.from_numpy(img), torch.from_numpy(msk)
     vx, vt = torch.from_numpy(vimg), torch.from_numpy(vmsk)
     g = torch.Generator().manual_seed(41)

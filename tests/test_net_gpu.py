@@ -27,22 +27,8 @@ def build(cfg, synth, dtype="fp32", unet=False):
     cls = nunet_amd.archs.UNet if unet else nunet_amd.archs.NestedUNet
     m = cls(ncls, cin, ds, dtype=dtype)
     st = synth.closed_form_state(ncls, cin, ds, fresh)
-    if unet:   # same hash generator, the U-Net's own shapes
-        st2, fan = {}, 1
-        for t_, (k, v) in enumerate(m.state_dict().items()):
-            u = synth._hash_uniform(max(1, v.numel()), 5000 + t_)
-            if k.endswith("conv1.weight") or k.endswith("conv2.weight") or k == "final.weight":
-                fan = v.shape[1] * v.shape[2] * v.shape[3]
-                st2[k] = (u / fan ** 0.5).reshape(v.shape).astype(np.float32)
-            elif k.endswith("conv1.bias") or k.endswith("conv2.bias") or k == "final.bias":
-                st2[k] = (u / fan ** 0.5).reshape(v.shape).astype(np.float32)
-            elif k.endswith("bn1.weight") or k.endswith("bn2.weight"):
-                st2[k] = (1 + 0.1 * u).astype(np.float32)
-            elif k.endswith("bn1.bias") or k.endswith("bn2.bias"):
-                st2[k] = (0.1 * u).astype(np.float32)
-            else:
-                st2[k] = v.numpy()
-        st = st2
+    if unet:   # same hash generator, the U-Net's own shapes (the state tests/golden/make_golden.py run_unet() loads)
+        st = synth.closed_form_state_unet(ncls, cin)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
     m = m.to(DEV)
     img, msk = synth.synth_batch(n, h, w, cin, ncls, seed=1234)
@@ -89,23 +75,17 @@ def test_fp32_matches_reference_goldens(name, synth):
     outs = out if ds else [out]
     # north_star: fp32 logits within 1e-4 of the reference. Where the reference's OWN fp32 logits are further than that
     # from an fp64 evaluation (BatchNorm over two 1x1 "images" at level 4 of the 16x16 case divides by a tiny std) the
-    # bound is 4x that conditioning error instead: summation order alone moves such a case by more than 1e-4.
-    # The same holds for the AMPLIFICATION of a relative input perturbation (measured on the fp64 oracle): the fp32
-    # atomics of the BatchNorm statistics reorder sums from run to run (~3e-7 relative), and the 16x16 case amplifies
-    # that ~1000x, so one run in six lands just outside 1e-4 although every kernel is exact to rounding.
+    # bound is 4x that conditioning error instead. (Every per-channel sum is order-independent fixed point and every
+    # other reduction has a fixed tree, so a run is bit-reproducible: no allowance for summation-order noise.)
     with torch.no_grad():
-        o64 = O.OracleNet(st, ncls, cin, ds, dtype=torch.float64)
-        l64 = o64(x.double())
+        l64 = O.OracleNet(st, ncls, cin, ds, dtype=torch.float64)(x.double())
         l32 = O.OracleNet(st, ncls, cin, ds, dtype=torch.float32)(x)
-        sign = torch.where(torch.rand(x.shape, generator=torch.Generator().manual_seed(3)) < 0.5, -1.0, 1.0).double()
-        l64p = o64(x.double() * (1.0 + 1e-6 * sign))
-    l64, l32, l64p = (l64 if ds else [l64]), (l32 if ds else [l32]), (l64p if ds else [l64p])
+    l64, l32 = (l64 if ds else [l64]), (l32 if ds else [l32])
     for k, o in enumerate(outs):
         ref = g["logits%d" % k]
         scale = max(1.0, float(np.abs(ref).max()))
         cond = float((l32[k].double() - l64[k]).abs().max()) / scale
-        amp = float((l64p[k] - l64[k]).abs().max()) / scale / 1e-6
-        assert float(np.abs(o.detach().cpu().numpy() - ref).max()) < max(1e-4, 4 * cond, 3e-7 * amp) * scale, (name, k, cond, amp)
+        assert float(np.abs(o.detach().cpu().numpy() - ref).max()) < max(1e-4, 4 * cond) * scale, (name, k, cond)
     assert abs(float(loss) - float(g["loss"])) < 2e-5
     # IoU is a hard threshold on logits: allow the flip of a handful of near-zero logits
     assert abs(iou - float(g["iou"])) < 5e-3
@@ -138,9 +118,19 @@ def test_fp32_matches_reference_goldens(name, synth):
         err_ref = float((g32 - g64).norm()) / (nrm + 1e-30)
         err_mine = float((mine - g64).norm()) / (nrm + 1e-30)
         worst = max(worst, err_mine)
-        assert err_mine < max(4 * err_ref, 2e-3), (nm, err_mine, err_ref)
-        # the golden (reference fp32) summary agrees too, within the reference's own conditioning
-        assert abs(float(mine.norm()) - g["grad_l2"][k]) < max(0.05, 4 * err_ref) * g["grad_l2"][k] + 1e-7, nm
+        assert err_mine < max(4 * err_ref, 1e-3), (nm, err_mine, err_ref)
+        # the golden (reference fp32) gradients agree too, within the reference's own conditioning: L2 norm, the 64
+        # strided samples of every tensor, and the full small tensors
+        tol = max(4 * err_ref, 1e-3)
+        assert abs(float(mine.norm()) - g["grad_l2"][k]) < tol * g["grad_l2"][k] + 1e-7, nm
+        flat = mine.reshape(-1)
+        stride = max(1, flat.numel() // 64)
+        smp = flat[::stride][:64].numpy()
+        gs = g["grad_sample"][k][:smp.size].astype(np.float64)
+        assert np.linalg.norm(smp - gs) < 3 * tol * max(np.linalg.norm(gs), g["grad_l2"][k] * (smp.size / flat.numel()) ** 0.5) + 1e-7, nm
+        if "grad/" + nm in g.files:
+            gfull = g["grad/" + nm].astype(np.float64)
+            assert np.linalg.norm(mine.numpy() - gfull) < tol * np.linalg.norm(gfull) + 1e-7, nm
     print(name, "worst grad rel err vs fp64 oracle:", worst)
 
 
@@ -207,6 +197,23 @@ def test_unet_matches_oracle(synth):
         d = net._block(torch.cat([xs[i], up], 1), i, 4 - i)
     ref = F.conv2d(d, net.params["final.weight"], net.params["final.bias"])
     assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 1e-4
+    # the reference's own U-Net (finished/archs1.py:35-71) on the same weights and inputs: golden logits, loss, IoU,
+    # BN running statistics and gradients
+    g = load_golden("h_unet_n2_32x32_k1")
+    assert float(np.abs(out.detach().cpu().numpy() - g["logits0"]).max()) < 1e-4 * max(1.0, float(np.abs(g["logits0"]).max()))
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    assert abs(iou - float(g["iou"])) < 5e-3
+    sd = m.state_dict()
+    for k, nm in enumerate(str(s_) for s_ in g["bn_names"]):
+        assert abs(float(sd[nm].double().sum()) - g["bn_sum"][k]) < 2e-4 * (1 + abs(g["bn_sum"][k])), nm
+    for k, (nm, p) in enumerate(m.named_parameters()):
+        assert nm == str(g["grad_names"][k])
+        if nm.endswith("conv1.bias") or nm.endswith("conv2.bias"):
+            continue
+        assert abs(float(p.grad.double().norm()) - g["grad_l2"][k]) < 2e-2 * g["grad_l2"][k] + 1e-7, nm
+        if "grad/" + nm in g.files:
+            gfull = g["grad/" + nm].astype(np.float64)
+            assert np.linalg.norm(p.grad.cpu().double().numpy() - gfull) < 2e-2 * np.linalg.norm(gfull) + 1e-7, nm
     l64 = O.bce_dice_loss(ref, t.double())
     l64.backward()
     assert abs(float(loss) - float(l64)) < 2e-5
@@ -275,8 +282,8 @@ def test_grad_accumulation_and_zero_grad_semantics(synth):
     named = [(k, p) for k, p in m.named_parameters() if not (k.endswith("conv1.bias") or k.endswith("conv2.bias"))]
     g1 = {k: a for (k, _), a in zip(m.named_parameters(), g1)}
 
-    def close(a, b):      # semantics check (x1 vs x2), robust to atomic-order noise on an ill-conditioned gradient
-        return float((a - b).norm()) <= 0.05 * float(b.norm()) + 1e-8
+    def close(a, b):      # semantics check (x1 vs x2); the second forward sees running-stat-independent batch statistics: same gradient
+        return float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-10
 
     for k, p in named:      # conv biases before BN have pure-noise gradients: skipped
         assert close(p.grad, 2 * g1[k]), k
@@ -315,19 +322,21 @@ def test_fused_train_step_graph_matches_eager_and_oracle(synth):
         assert float((w - rw).abs().max()) < 2e-5
 
 
-def test_training_log_follows_reference(synth):
-    """'val IoU vs ref' in its offline form: the reference model/loss/metric trained on the
-    seeded blob set (tests/golden/make_golden.py trainlog: SGD 1e-2, momentum 0.9, wd 1e-4, cosine, 6 epochs
-    of 256 images, bs 16, 96x96) vs the same loop on the HIP path (same init seed, same shuffle stream)."""
+@pytest.mark.parametrize("dtype,iou_band", [("fp32", 0.02), ("bf16", 0.03)])
+def test_training_log_follows_reference(dtype, iou_band, synth):
+    """'val IoU vs ref' (BASELINE.json metric, second half) in its offline form: the REFERENCE
+    model/loss/metric trained on the seeded learnable blob set (tests/golden/make_golden.py trainlog: SGD 1e-2,
+    momentum 0.9, wd 1e-4, cosine, 30 epochs of 512 images, bs 16, 96x96, validation on 128 held-out images,
+    reference trains.py:106-188,321,331-339) vs the same loop on the HIP path (same init seed, same shuffle stream)."""
     from nunet_amd.trainer import TrainStep, cosine_lr
     from nunet_amd.metrics import iou_counts, iou_from_counts
     g = load_golden("train_log_blobs")
     ref = g["log"]
     epochs, train_size, val_size, bs, hw, lr = (int(v) if k < 5 else float(v) for k, v in enumerate(g["config"]))
     torch.manual_seed(41)
-    m = nunet_amd.archs.NestedUNet(1, 3, False).to(DEV).train()
-    img, msk = synth.synth_batch(train_size, hw, hw, 3, 1, seed=1000)
-    vimg, vmsk = synth.synth_batch(val_size, hw, hw, 3, 1, seed=2000)
+    m = nunet_amd.archs.NestedUNet(1, 3, False, dtype=dtype).to(DEV).train()
+    img, msk = synth.synth_blob_pairs(train_size, hw, hw, seed=1000)
+    vimg, vmsk = synth.synth_blob_pairs(val_size, hw, hw, seed=2000)
     x, t = torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV)
     vx, vt = torch.from_numpy(vimg).to(DEV), torch.from_numpy(vmsk).to(DEV)
     ts = TrainStep(m, (bs, 3, hw, hw), lr=lr, momentum=0.9, weight_decay=1e-4)
@@ -352,19 +361,110 @@ def test_training_log_follows_reference(synth):
                 vl += float(crit(o, vt[k:k + bs].contiguous())) * bs
                 vi += iou_from_counts(iou_counts(o.contiguous(), vt[k:k + bs].contiguous())) * bs
         rows.append((tl, ti, vl / val_size, vi / val_size))
-        print("epoch", ep, "hip", rows[-1], "ref", tuple(ref[ep][2:]))
+        print("epoch", ep, dtype, "hip", rows[-1], "ref", tuple(ref[ep][2:]))
     rows = np.array(rows)
-    # the loop is chaotic at the 1e-2 level after ~100 steps; bands, not equality
-    assert abs(ref[0][1] - lr) < 1e-12
-    assert np.all(np.abs(rows[:, 0] - ref[:, 2]) < 0.05), (rows[:, 0], ref[:, 2])          # train loss per epoch
-    assert np.all(np.abs(rows[:, 1] - ref[:, 3]) < 0.10), (rows[:, 1], ref[:, 3])          # train IoU per epoch
-    assert rows[-1, 0] < rows[0, 0] - 0.2                                                  # it learns
-    # val loss: eval-mode BN with running statistics that lag the fast-moving early weights makes single epochs
-    # jump by +-0.4 from run to run (fp32 atomic order is enough to move them), in the reference as well; the band
-    # holds for the first epoch (before any divergence), the last one (converging), and the median of all
-    dv = np.abs(rows[:, 2] - ref[:, 4])
-    assert dv[0] < 0.05 and dv[-1] < 0.30 and np.median(dv) < 0.15, (rows[:, 2], ref[:, 4])
-    assert np.all(np.isfinite(rows)) and rows[:, 2].max() < 2.0
+    assert abs(ref[0][1] - lr) < 1e-12 and np.all(np.isfinite(rows))
+    # the metric itself: validation IoU, mean of the last five epochs, against the reference's
+    ref_iou, hip_iou = float(ref[-5:, 5].mean()), float(rows[-5:, 3].mean())
+    assert ref_iou > 0.6, "fixture: the reference itself did not learn the task"
+    assert abs(hip_iou - ref_iou) <= iou_band, (hip_iou, ref_iou)
+    # per epoch once both have converged (the early epochs, where eval-mode BN lags fast-moving weights, swing in the
+    # reference too): second half of the schedule
+    half = epochs // 2
+    assert np.all(np.abs(rows[half:, 3] - ref[half:, 5]) <= 2 * iou_band), (rows[half:, 3], ref[half:, 5])
+    assert np.all(np.abs(rows[half:, 2] - ref[half:, 4]) <= 0.05), (rows[half:, 2], ref[half:, 4])            # val loss
+    # training side: first epoch (no divergence yet) tightly, every epoch in a band, and it learns
+    assert abs(rows[0, 0] - ref[0, 2]) < 0.03 and abs(rows[0, 1] - ref[0, 3]) < 0.05, (rows[0], ref[0])
+    assert np.all(np.abs(rows[:, 0] - ref[:, 2]) < 0.08), (rows[:, 0], ref[:, 2])
+    assert np.all(np.abs(rows[half:, 1] - ref[half:, 3]) < 2 * iou_band), (rows[half:, 1], ref[half:, 3])
+    assert rows[-1, 0] < 0.5 * rows[0, 0]
+
+
+def test_cfg2_bf16_bs16_96_training_follows_oracle(synth):
+    """BASELINE.json configs[1] itself (bf16 storage, batch 16, 96x96, BCEDiceLoss, SGD defaults) through the
+    hipGraph TrainStep, against the fp32 CPU oracle running the same loop (reference trains.py:113-135,229-231):
+    per-step loss over 20 steps, and every parameter gradient of the first step against the fp64 oracle."""
+    from nunet_amd.trainer import TrainStep
+    n, hw, steps = 16, 96, 20
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, False).state_dict().items()}   # default init (reference init)
+    batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=1234 + k) for k in range(4)]
+    m = nunet_amd.archs.NestedUNet(1, 3, False, dtype="bf16")
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    ts = TrainStep(m, (n, 3, hw, hw), keep_grads=True)
+    ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+    hip, grads0 = [], None
+    for k in range(steps):
+        img, msk = batches[k % 4]
+        ts.reset_meters()
+        ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+        hip.append(ts.epoch_stats()[0])
+        if k == 0:
+            grads0 = {nm: p.grad.detach().cpu().double().clone() for nm, p in m.named_parameters()}
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    st = {k: v.numpy() for k, v in sd.items()}
+    net = O.OracleNet(st, 1, 3, False)
+    opt = O.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    ref = [O.train_step(net, opt, torch.from_numpy(batches[k % 4][0]), torch.from_numpy(batches[k % 4][1]))[0] for k in range(steps)]
+    print("hip", " ".join("%.4f" % v for v in hip)); print("ref", " ".join("%.4f" % v for v in ref))
+    assert np.all(np.isfinite(hip))
+    assert np.max(np.abs(np.array(hip) - np.array(ref))) < 1e-3, (hip, ref)
+    assert abs(hip[0] - ref[0]) < 5e-4
+    # Gradients of step 0. Against the UNROUNDED fp64 network 16-bit storage leaves large per-tensor errors at
+    # initialisation: the loss gradient is nearly orthogonal to the features (d gamma = sum dz * xhat is a correlation
+    # that almost cancels), so the fp32 reference itself is ~1e-5 off and bf16's 2^16 x coarser rounding reaches tens of
+    # percent - a property of the storage format, not of the kernels. The kernel statement is therefore made against the
+    # fp64 oracle with THE SAME 16-bit storage points emulated (oracle storage=bfloat16: packed weights, raw conv outputs,
+    # activations, upsampled / pooled tensors and all their gradients rounded, exact arithmetic in between).
+    x0, t0 = torch.from_numpy(batches[0][0]).double(), torch.from_numpy(batches[0][1]).double()
+    o64 = O.OracleNet(st, 1, 3, False, dtype=torch.float64)
+    O.bce_dice_loss(o64(x0), t0).backward()
+    e64 = O.OracleNet(st, 1, 3, False, dtype=torch.float64, storage=torch.bfloat16)
+    le = O.bce_dice_loss(e64(x0), t0)
+    le.backward()
+    assert abs(hip[0] - float(le)) < 2e-4
+    errs, errs_plain = {}, {}
+    for nm, gmine in grads0.items():
+        if nm.endswith("conv1.bias") or nm.endswith("conv2.bias"):
+            assert float(gmine.abs().max()) == 0.0, nm          # exact zeros: bias in front of a BatchNorm
+            continue
+        ge, g64 = e64.params[nm].grad, o64.params[nm].grad
+        errs[nm] = float((gmine - ge).norm() / (ge.norm() + 1e-30))
+        errs_plain[nm] = float((gmine - g64).norm() / (g64.norm() + 1e-30))
+    worst = max(errs, key=errs.get)
+    print("bf16 bs16 grad rel-L2 vs bf16-storage oracle: max %.4f (%s) median %.4f; vs unrounded fp64: max %.4f median %.4f" %
+          (errs[worst], worst, float(np.median(list(errs.values()))), max(errs_plain.values()), float(np.median(list(errs_plain.values())))))
+    assert errs[worst] < 1e-1, (worst, errs[worst])
+    assert float(np.median(list(errs.values()))) < 3e-2
+    assert max(errs_plain.values()) < 0.8 and float(np.median(list(errs_plain.values()))) < 0.4
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_training_step_is_bit_reproducible(dtype, synth):
+    """SURVEY.md §5.2 determinism check: two independent runs of three bs16 96x96 training steps (hipGraph, multi-lane)
+    end with bit-identical parameters, BatchNorm buffers, momentum, loss and gradients. Every reduction has a fixed
+    order (weight-gradient slabs, split-K slabs, head slabs, loss slabs) or is order-independent (fixed-point
+    per-channel sums)."""
+    from nunet_amd.trainer import TrainStep
+    n, hw = 16, 96
+    torch.manual_seed(3)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, True).state_dict().items()}
+    batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=77 + k) for k in range(3)]
+    outs = []
+    for run in range(2):
+        m = nunet_amd.archs.NestedUNet(1, 3, True, dtype=dtype)       # deep supervision: four heads write GX[0] slots
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, keep_grads=True)
+        ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+        for img, msk in batches:
+            ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (ts.eng.flat_params, ts.eng.bnbuf, ts.eng.nbt, ts.mom, ts.eng.flat_grads, ts.loss_out, ts.meters)])
+        del ts, m
+    for a, b, nm in zip(outs[0], outs[1], ("params", "bn buffers", "nbt", "momentum", "grads", "loss", "meters")):
+        assert torch.equal(a, b), nm
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -401,5 +501,4 @@ def test_fused_update_equals_unpack_sgd_pack(dtype, mode, synth):
         l1 = ts.logits.clone()
         ts._packed = False
         ts._fwd_loss()                             # repacks from the fp32 parameters
-        # (two training-mode forwards: the BatchNorm statistics are summed with atomics, so not bit-identical)
-        assert float((l1 - ts.logits).abs().max()) <= (1e-4 if dtype == "fp32" else 2e-2) * float(l1.abs().max())
+        assert torch.equal(l1, ts.logits)          # same packed weights, deterministic reductions: bit-identical

@@ -65,7 +65,7 @@ def conv_desc(dt, n, h, w, src0, c0, p0, wpack, dst0, d0, q0, src1=None, c1=0, p
     (2, 20, 24, 32, 0, 32),     # BN=32 config, ragged tiles
     (1, 16, 16, 64, 64, 64),    # two sources, BN=64 config
     (5, 6, 6, 32, 0, 64),       # multi-image tiles
-    (2, 8, 40, 16, 0, 32),      # Cin = 16 (single half chunk)
+    (2, 8, 40, 96, 0, 32),      # three channel chunks from one source
     (1, 2, 2, 64, 32, 96),      # tiny spatial, Cout = 96 -> BN=32 config
     (3, 1, 1, 32, 0, 32),       # 1x1 images (level 4 of a 16x16 input)
     (16, 12, 12, 64, 32, 64),   # 12x12 images: stacked-rows tiling (level 3 of the 96x96 workload)
@@ -84,7 +84,7 @@ def test_conv3x3_fwd(dt, shape):
     s1 = nhwc(x[:, c0:], dt) if c1 else None
     wf, _ = pack(wt, dt)
     y = torch.full((n, h, w, cout), 7.0, dtype=tdt(dt), device=DEV)
-    stats = torch.zeros(L.BN_SUM_REPLICAS * 2 * cout, dtype=torch.float32, device=DEV)
+    stats = L.fx_zeros(cout, DEV)
     bg = b.to(DEV)
     d = conv_desc(dt, n, h, w, s0, c0, c0 + 32, wf, y, cout, cout, src1=s1, c1=c1, p1=c1, bias=bg, stats=stats)
     L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "conv")
@@ -93,7 +93,7 @@ def test_conv3x3_fwd(dt, shape):
     assert rel_err(got, ref) < TOL[dt], (DT[dt], shape)
     # BN partial sums are taken about the bias on the rounded outputs
     dd = got.double() - b.double().view(1, -1, 1, 1)
-    s = stats.cpu().double().view(L.BN_SUM_REPLICAS, 2 * cout).sum(0)
+    s = L.fx_decode(stats, cout)
     m = n * h * w
     np.testing.assert_allclose(s[:cout].numpy() / m, dd.sum((0, 2, 3)).numpy() / m, atol=1e-4 * float(dd.abs().max()) + 1e-6)
     np.testing.assert_allclose(s[cout:].numpy() / m, (dd * dd).sum((0, 2, 3)).numpy() / m, rtol=1e-3, atol=1e-6)
@@ -142,9 +142,7 @@ def test_conv3x3_wgrad(dt, shape):
     s0 = nhwc(x[:, :c0], dt, pitch=c0 + 64)
     s1 = nhwc(x[:, c0:], dt) if c1 else None
     dyb = nhwc(dy, dt)
-    dw = torch.zeros(9 * cout * cin, dtype=torch.float32, device=DEV)
-    d = L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, c0 + 64, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(dw))
-    L.check(L.lib().nunet_conv3x3_wgrad(C.byref(d), L.stream()), "wgrad")
+    dw = wgrad_run(dt, n, h, w, s0, c0, c0 + 64, s1, c1, dyb, cout)
     wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(q(x, dt).double(), wt, padding=1).backward(q(dy, dt).double())
     gout = torch.zeros(cout * cin * 9, dtype=torch.float32, device=DEV)
@@ -154,6 +152,25 @@ def test_conv3x3_wgrad(dt, shape):
 
 
 
+def wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, slabs, max_slabs=0, target=0):
+    return L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, p0, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(slabs),
+                       9 * cout * (c0 + c1), max_slabs, target)
+
+
+def wgrad_run(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, target=0):
+    """K-split slabs (plain stores, every slab fully overwritten: pre-filled with garbage) + the fixed-order reduce."""
+    cin = c0 + c1
+    probe = wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, None, 0, target)
+    ks = L.lib().nunet_conv3x3_wgrad_slabs(C.byref(probe))
+    assert ks >= 1
+    slabs = torch.full((ks * 9 * cout * cin,), 1e30, dtype=torch.float32, device=DEV)
+    d = wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, slabs, ks, target)
+    L.check(L.lib().nunet_conv3x3_wgrad(C.byref(d), L.stream()), "wgrad")
+    dw = torch.full((9 * cout * cin,), 3.0, dtype=torch.float32, device=DEV)
+    L.check(L.lib().nunet_wgrad_reduce(L.ptr(slabs), 9 * cout * cin, ks, 9 * cout * cin, L.ptr(dw), 0, L.stream()), "wgrad_reduce")
+    return dw
+
+
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 def test_conv3x3_wgrad_pair(dt):
     """Two independent weight-gradient problems in one launch equal two single launches
@@ -161,7 +178,7 @@ def test_conv3x3_wgrad_pair(dt):
     n, h, w = 3, 12, 12
     g = torch.Generator().manual_seed(5)
     probs = [(64, 32, 64), (64, 0, 64)]        # (C0, C1, Cout): conv1 with a concat input, conv2 mid -> out
-    descs, keep, refs, dws = [], [], [], []
+    descs, keep, refs, slabs_l, kss = [], [], [], [], []
     for c0, c1, cout in probs:
         cin = c0 + c1
         x = torch.randn(n, cin, h, w, generator=g)
@@ -169,19 +186,21 @@ def test_conv3x3_wgrad_pair(dt):
         s0 = nhwc(x[:, :c0], dt, pitch=c0 + 32)
         s1 = nhwc(x[:, c0:], dt) if c1 else None
         dyb = nhwc(dy, dt)
-        dw = torch.zeros(9 * cout * cin, dtype=torch.float32, device=DEV)
         keep += [s0, s1, dyb]
-        dws.append(dw)
-        descs.append(L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, c0 + 32, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(dw)))
-        ref = torch.zeros_like(dw)
-        d1 = L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, c0 + 32, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(ref))
-        L.check(L.lib().nunet_conv3x3_wgrad(C.byref(d1), L.stream()), "wgrad")
-        refs.append(ref)
+        refs.append(wgrad_run(dt, n, h, w, s0, c0, c0 + 32, s1, c1, dyb, cout, target=128))
+        probe = wgrad_desc(dt, n, h, w, s0, c0, c0 + 32, s1, c1, dyb, cout, None, 0, 128)
+        ks = L.lib().nunet_conv3x3_wgrad_slabs(C.byref(probe))
+        slabs = torch.full((ks * 9 * cout * cin,), -7.0, dtype=torch.float32, device=DEV)
+        slabs_l.append(slabs); kss.append(ks)
+        descs.append(wgrad_desc(dt, n, h, w, s0, c0, c0 + 32, s1, c1, dyb, cout, slabs, ks, 128))
     L.check(L.lib().nunet_conv3x3_wgrad_pair(C.byref(descs[0]), C.byref(descs[1]), L.stream()), "wgrad_pair")
-    torch.cuda.synchronize()
-    for dw, ref in zip(dws, refs):
+    for (c0, c1, cout), slabs, ks, ref in zip(probs, slabs_l, kss, refs):
+        nw = 9 * cout * (c0 + c1)
+        dw = torch.zeros(nw, dtype=torch.float32, device=DEV)
+        L.check(L.lib().nunet_wgrad_reduce(L.ptr(slabs), nw, ks, nw, L.ptr(dw), 0, L.stream()), "wgrad_reduce")
         assert float(ref.abs().max()) > 0
-        assert rel_err(dw.cpu(), ref.cpu()) < 1e-5      # same arithmetic, only the atomic order differs
+        assert torch.equal(dw, ref)      # same slices, same summation order: bit-identical
+
 
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 def test_pack_unpack_roundtrip(dt):
@@ -219,9 +238,7 @@ def test_bn_relu_fwd(dt, pool, training):
     rv = 0.5 + torch.rand(c, generator=g)
     yb = nhwc(ys, dt)
     dd = ys.double()
-    stats = torch.zeros(L.BN_SUM_REPLICAS * 2 * c, dtype=torch.float32)
-    stats[:2 * c] = torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3))]).float()     # replica 0 holds everything
-    stats = stats.to(DEV)
+    stats = L.fx_encode(torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3))]), c, DEV)     # replica 0 holds everything
     a = torch.zeros((n, h, w, 160), dtype=tdt(dt), device=DEV)
     pooled = torch.zeros((n, h // 2, w // 2, c), dtype=tdt(dt), device=DEV) if pool else None
     rmg, rvg = rm.clone().to(DEV), rv.clone().to(DEV)
@@ -268,10 +285,10 @@ def test_bn_relu_bwd(dt):
     mi = torch.cat([mean, istd]).float().to(DEV)
     yb = nhwc(y, dt)
     dab = nhwc(da, dt, pitch=160, off=64)
-    sums = torch.zeros(L.BN_SUM_REPLICAS * 2 * c, dtype=torch.float32, device=DEV)
-    dg = torch.zeros(c, dtype=torch.float32, device=DEV)
-    db = torch.zeros(c, dtype=torch.float32, device=DEV)
-    dbias = torch.zeros(c, dtype=torch.float32, device=DEV)
+    sums = L.fx_zeros(c, DEV)
+    dg = torch.full((c,), 9.0, dtype=torch.float32, device=DEV)      # assigned, not accumulated
+    db = torch.full((c,), 9.0, dtype=torch.float32, device=DEV)
+    dbias = torch.full((c,), 9.0, dtype=torch.float32, device=DEV)
     dyb = torch.zeros((n, h, w, c), dtype=tdt(dt), device=DEV)
     gamma_g, beta_g = gamma.to(DEV), beta.to(DEV)
     d = L.BnBwdDesc(dt, n, h, w, c, L.ptr(dab, 64 * dab.element_size()), 160, L.ptr(yb), c, L.ptr(mi),
@@ -281,8 +298,8 @@ def test_bn_relu_bwd(dt):
     L.check(L.lib().nunet_bn_relu_bwd_apply(C.byref(d), L.stream()), "bn bwd apply")
     assert rel_err(to_nchw(dyb, c), yd.grad) < TOL[dt]
     assert rel_err(dg.cpu(), gd.grad) < 1e-4 and rel_err(db.cpu(), bd.grad) < 1e-4
-    # conv-bias gradient = sum of dy, analytically ~0; must be tiny relative to |dy| mass
-    assert float(dbias.abs().max()) < 2e-2 * float(yd.grad.abs().sum((0, 2, 3)).max())
+    # conv-bias gradient = sum of dy = 0 analytically (a bias in front of a BatchNorm): stored as exact zeros
+    assert float(dbias.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
@@ -304,7 +321,7 @@ def test_conv3x3_fused_bn_bwd_reduce(dt, shape, sk):
     wf, _ = pack(wt, dt)
     yb = nhwc(y1, dt)
     out = torch.zeros((n, h, w, cout), dtype=tdt(dt), device=DEV)
-    sums = torch.zeros(L.BN_SUM_REPLICAS * 2 * cout, dtype=torch.float32, device=DEV)
+    sums = L.fx_zeros(cout, DEV)
     gamma_g, beta_g = gamma.to(DEV), beta.to(DEV)
     d = conv_desc(dt, n, h, w, s0, cin, cin, wf, out, cout, cout)
     ws = None
@@ -324,8 +341,8 @@ def test_conv3x3_fused_bn_bwd_reduce(dt, shape, sk):
     ref = F.conv2d(q(x, dt).double(), q(wt, dt).double(), padding=1)
     assert rel_err(to_nchw(out, cout), ref) < TOL[dt]
     assert float(ref_sums.abs().max()) > 0
-    tot = sums.view(L.BN_SUM_REPLICAS, 2 * cout).sum(0)
-    rtot = ref_sums.view(L.BN_SUM_REPLICAS, 2 * cout).sum(0)
+    tot = L.fx_decode(sums, cout)
+    rtot = L.fx_decode(ref_sums, cout)
     scale = float(rtot.abs().max())
     assert float((tot - rtot).abs().max()) < 2e-4 * scale + 1e-5, (DT[dt], shape)
 
@@ -482,12 +499,11 @@ def test_conv3x3_splitk_slabs(dt):
     prev = torch.randn(n, cout, h, w, generator=g)
     s0, s1 = nhwc(x[:, :c0], dt), nhwc(x[:, c0:], dt)
     wf, _ = pack(wt, dt)
-    ws = torch.full((8 * n * h * w * cout + 256,), 7.0, dtype=torch.float32, device=DEV)   # garbage: slabs are fully overwritten
-    ws[:256] = 0                                                                           # ... but the arrival counters start at zero
-    outs = []
+    ws = torch.full((8 * n * h * w * cout,), 7.0, dtype=torch.float32, device=DEV)   # garbage: slabs are fully overwritten
+    outs, sts = [], []
     for accum in (0, 1, 0):
         y = nhwc(prev, dt)
-        stats = torch.zeros(L.BN_SUM_REPLICAS * 2 * cout, dtype=torch.float32, device=DEV)
+        stats = L.fx_zeros(cout, DEV)
         d = conv_desc(dt, n, h, w, s0, c0, c0, wf, y, cout, cout, src1=s1, c1=c1, p1=c1, stats=stats,
                       slot_w=cout, mask=accum)
         d.splitk_ws = L.ptr(ws).value
@@ -499,10 +515,158 @@ def test_conv3x3_splitk_slabs(dt):
         if not accum:
             got = to_nchw(y, cout).double()
             m = n * h * w
-            tot = stats.view(L.BN_SUM_REPLICAS, 2 * cout).sum(0)
-            np.testing.assert_allclose(tot[:cout].cpu().numpy() / m, got.sum((0, 2, 3)).numpy() / m, atol=1e-4)
-            outs.append(y.clone())
+            tot = L.fx_decode(stats, cout)
+            np.testing.assert_allclose(tot[:cout].numpy() / m, got.sum((0, 2, 3)).numpy() / m, atol=1e-4)
+            outs.append(y.clone()); sts.append(stats.clone())
     assert torch.equal(outs[0], outs[1])
+    assert torch.equal(sts[0].view(L.BN_SUM_REPLICAS, -1).sum(0), sts[1].view(L.BN_SUM_REPLICAS, -1).sum(0))   # integer sums: exact
+
+
+def test_conv3x3_rejects_partial_channel_chunks():
+    """C0 / C1 must be whole 64-byte channel chunks (the staging has no ragged path): loud error, no silent padding."""
+    x = torch.zeros((1, 4, 4, 16), dtype=torch.bfloat16, device=DEV)
+    wf = torch.zeros(9 * 32 * 16, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16, device=DEV)
+    d = conv_desc(L.BF16, 1, 4, 4, x, 16, 16, wf, y, 32, 32)
+    assert L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()) == -1
+    assert b"multiples of 32" in L.lib().nunet_last_error()
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(2, 20, 24, 32, 32), (3, 12, 12, 64, 64), (16, 6, 6, 512, 512), (5, 12, 12, 32, 32)])
+def test_conv3x3_input_transform_bn_relu(dt, training, shape):
+    """NUNET_TF_BN_RELU: conv(relu(bn(y1))) with the BatchNorm applied on the way into LDS equals bn_relu_fwd followed
+    by the plain conv (reference finished/archs1.py:23-28), bit for bit; the side-stored activation, the saved
+    statistics and the running-statistics update equal bn_relu_fwd's."""
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(23)
+    y1 = q(torch.randn(n, cin, h, w, generator=g) * 0.8 + 0.3, dt)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = (torch.randn(cin, generator=g) * 0.3).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(cin, generator=g)).to(DEV)
+    gamma[1] = -gamma[1]                                           # a negative scale must work too
+    beta = (0.2 * torch.randn(cin, generator=g)).to(DEV)
+    rm0, rv0 = 0.1 * torch.randn(cin, generator=g), 0.5 + torch.rand(cin, generator=g)
+    yb = nhwc(y1, dt)
+    dd = y1.double()
+    stats = L.fx_encode(torch.cat([dd.sum((0, 2, 3)), (dd * dd).sum((0, 2, 3))]), cin, DEV)
+    wf, _ = pack(wt, dt)
+    # reference path: stand-alone BN kernel, then the plain conv
+    a_ref = torch.zeros((n, h, w, cin), dtype=tdt(dt), device=DEV)
+    rm_a, rv_a = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    nbt_a = torch.tensor([2], dtype=torch.int64, device=DEV)
+    save_a = torch.zeros(2 * cin, dtype=torch.float32, device=DEV)
+    b = L.BnFwdDesc(dt, n, h, w, cin, L.ptr(yb), cin, L.ptr(bias), L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+                    L.ptr(rm_a), L.ptr(rv_a), L.ptr(nbt_a), L.ptr(save_a), 1 if training else 0, 0.1, 1e-5,
+                    L.ptr(a_ref), cin, None, 0)
+    L.check(L.lib().nunet_bn_relu_fwd(C.byref(b), L.stream()), "bn")
+    out_ref = torch.zeros((n, h, w, cout), dtype=tdt(dt), device=DEV)
+    d0 = conv_desc(dt, n, h, w, a_ref, cin, cin, wf, out_ref, cout, cout)
+    ws = torch.zeros(8 * n * h * w * cout, dtype=torch.float32, device=DEV)
+    d0.splitk_ws = L.ptr(ws).value; d0.splitk_ws_floats = ws.numel()
+    L.check(L.lib().nunet_conv3x3_fwd(C.byref(d0), L.stream()), "conv")
+    # fused path
+    out = torch.zeros_like(out_ref)
+    a_side = torch.full((n, h, w, cin), 5.0, dtype=tdt(dt), device=DEV)
+    rm_b, rv_b = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    nbt_b = torch.tensor([2], dtype=torch.int64, device=DEV)
+    save_b = torch.zeros(2 * cin, dtype=torch.float32, device=DEV)
+    st2 = L.fx_zeros(cout, DEV)
+    d = conv_desc(dt, n, h, w, yb, cin, cin, wf, out, cout, cout, stats=st2)
+    d.splitk_ws = L.ptr(ws).value; d.splitk_ws_floats = ws.numel()
+    d.in_tf = L.TF_BN_RELU; d.tf_training = 1 if training else 0
+    d.tf_fx = L.ptr(stats).value; d.tf_gamma = L.ptr(gamma).value; d.tf_beta = L.ptr(beta).value; d.tf_conv_bias = L.ptr(bias).value
+    d.tf_running_mean = L.ptr(rm_b).value; d.tf_running_var = L.ptr(rv_b).value; d.tf_nbt = L.ptr(nbt_b).value
+    d.tf_mean_invstd = L.ptr(save_b).value; d.tf_momentum = 0.1; d.tf_eps = 1e-5
+    d.tf_store = L.ptr(a_side).value; d.tf_ps = cin
+    L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "conv+tf")
+    torch.cuda.synchronize()
+    assert float(a_ref.float().abs().max()) > 0
+    assert torch.equal(a_side, a_ref)                       # every pixel stored exactly once, same rounding
+    assert torch.equal(out, out_ref)
+    assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b) and torch.equal(save_a, save_b) and torch.equal(nbt_a, nbt_b)
+    assert int(nbt_b.item()) == (3 if training else 2)
+    # and against torch: conv(relu(bn(y1 + bias)))
+    yfull = (y1 + bias.cpu().view(1, -1, 1, 1)).double()
+    a64 = F.relu(F.batch_norm(yfull, rm0.clone().double(), rv0.clone().double(), gamma.cpu().double(), beta.cpu().double(), training, 0.1, 1e-5))
+    ref = F.conv2d(q(a64.float(), dt).double(), q(wt, dt).double(), padding=1)
+    assert rel_err(to_nchw(out, cout), ref) < 4 * TOL[dt]
+    m = n * h * w
+    got = to_nchw(out, cout).double()
+    tot = L.fx_decode(st2, cout)
+    np.testing.assert_allclose(tot[:cout].numpy() / m, got.sum((0, 2, 3)).numpy() / m, atol=1e-4 * float(got.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
+@pytest.mark.parametrize("shape", [(2, 20, 24, 32, 96), (3, 12, 12, 64, 64), (16, 6, 6, 512, 256), (5, 12, 12, 32, 32)])
+def test_conv3x3_input_transform_bn_relu_bwd(dt, shape):
+    """NUNET_TF_BN_RELU_BWD: dgrad with the BatchNorm+ReLU backward APPLY pass taken on the way into LDS equals
+    nunet_bn_relu_bwd_apply followed by the plain dgrad, bit for bit; the side-stored dy (for the weight gradient)
+    and d gamma / d beta / d bias equal the stand-alone kernel's."""
+    n, h, w, c, cout = shape          # c: channels of the BatchNorm (= Cin of the dgrad conv)
+    g = torch.Generator().manual_seed(29)
+    y = q(torch.randn(n, c, h, w, generator=g), dt)
+    da = q(torch.randn(n, c, h, w, generator=g), dt)
+    wt = torch.randn(cout, c, 3, 3, generator=g) / (3 * c ** 0.5)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(DEV)
+    beta = (0.2 * torch.randn(c, generator=g)).to(DEV)
+    mean = y.double().mean((0, 2, 3))
+    istd = 1 / (y.double().var((0, 2, 3), unbiased=False) + 1e-5).sqrt()
+    mi = torch.cat([mean, istd]).float().to(DEV)
+    yb = nhwc(y, dt)
+    dab = nhwc(da, dt, pitch=c + 64, off=32)               # the gradient lives in a slot of a wider level buffer
+    da_ptr = L.ptr(dab, 32 * dab.element_size())
+    sums = L.fx_zeros(c, DEV)
+    vec = [torch.full((c,), 9.0, dtype=torch.float32, device=DEV) for _ in range(6)]
+    dy_ref = torch.zeros((n, h, w, c), dtype=tdt(dt), device=DEV)
+    b = L.BnBwdDesc(dt, n, h, w, c, da_ptr, c + 64, L.ptr(yb), c, L.ptr(mi), L.ptr(gamma), L.ptr(beta), L.ptr(sums),
+                    L.ptr(vec[0]), L.ptr(vec[1]), L.ptr(vec[2]), L.ptr(dy_ref), c)
+    L.check(L.lib().nunet_bn_relu_bwd_reduce(C.byref(b), L.stream()), "reduce")
+    L.check(L.lib().nunet_bn_relu_bwd_apply(C.byref(b), L.stream()), "apply")
+    wf, _ = pack(wt, dt)                                      # any packed [9][cout][c] weights do
+    ws = torch.zeros(8 * n * h * w * cout, dtype=torch.float32, device=DEV)
+    out_ref = torch.zeros((n, h, w, cout), dtype=tdt(dt), device=DEV)
+    d0 = conv_desc(dt, n, h, w, dy_ref, c, c, wf, out_ref, cout, cout)
+    d0.splitk_ws = L.ptr(ws).value; d0.splitk_ws_floats = ws.numel()
+    L.check(L.lib().nunet_conv3x3_fwd(C.byref(d0), L.stream()), "dgrad")
+    out = torch.zeros_like(out_ref)
+    dy_side = torch.full((n, h, w, c), 5.0, dtype=tdt(dt), device=DEV)
+    d = L.ConvDesc()
+    d.dtype = dt; d.N = n; d.H = h; d.W = w
+    d.src0 = da_ptr.value; d.C0 = c; d.P0 = c + 64
+    d.wpack = L.ptr(wf).value; d.dst0 = L.ptr(out).value; d.D0 = cout; d.Q0 = cout
+    d.splitk_ws = L.ptr(ws).value; d.splitk_ws_floats = ws.numel()
+    d.in_tf = L.TF_BN_RELU_BWD; d.tf_y = L.ptr(yb).value; d.tf_py = c; d.tf_fx = L.ptr(sums).value
+    d.tf_gamma = L.ptr(gamma).value; d.tf_beta = L.ptr(beta).value; d.tf_mean_invstd = L.ptr(mi).value
+    d.tf_dgamma = L.ptr(vec[3]).value; d.tf_dbeta = L.ptr(vec[4]).value; d.tf_dbias = L.ptr(vec[5]).value
+    d.tf_store = L.ptr(dy_side).value; d.tf_ps = c
+    L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "dgrad+tf")
+    torch.cuda.synchronize()
+    assert float(dy_ref.float().abs().max()) > 0
+    assert torch.equal(dy_side, dy_ref)
+    assert torch.equal(out, out_ref)
+    for k in range(3):
+        assert torch.equal(vec[k], vec[3 + k])
+    assert float(vec[5].abs().max()) == 0.0
+
+
+def test_per_channel_sums_are_order_independent():
+    """Fixed-point per-channel sums: the BatchNorm statistics a conv leaves are bit-identical from launch to launch
+    (fp32 atomics would depend on the arrival order of 576 workgroups)."""
+    n, h, w, cin, cout = 16, 96, 96, 32, 32
+    g = torch.Generator().manual_seed(31)
+    x = nhwc(torch.randn(n, cin, h, w, generator=g), L.BF16)
+    wf, _ = pack(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), L.BF16)
+    tots = []
+    for _ in range(3):
+        y = torch.zeros((n, h, w, cout), dtype=torch.bfloat16, device=DEV)
+        st = L.fx_zeros(cout, DEV)
+        d = conv_desc(L.BF16, n, h, w, x, cin, cin, wf, y, cout, cout, stats=st)
+        L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream()), "conv")
+        tots.append(st.view(L.BN_SUM_REPLICAS, -1).sum(0).clone())
+    assert torch.equal(tots[0], tots[1]) and torch.equal(tots[0], tots[2])
+    assert float(L.fx_decode(st, cout)[cout:].min()) > 0
 
 
 def test_lovasz_hinge_against_reference_goldens():
