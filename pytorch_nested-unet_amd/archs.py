@@ -47,10 +47,10 @@ class _PlanNet(nn.Module):
         self.compute_dtype = L.DTYPES[dt]
         self._engine = None
 
-    # any device/dtype move re-homes the flat arenas at the next forward
-    def _apply(self, fn, *a, **k):
-        self._engine = None
-        return super()._apply(fn, *a, **k)
+    # A device move (.cuda() / .to(dev)) swaps the parameters' storage: engine() notices (device change or the
+    # parameters no longer being views of its arenas, Engine.intact()) and re-homes them at the next forward. A call
+    # that moves nothing (.cuda() on a module already there, .float()) leaves the arenas - and everything that holds
+    # pointers into them: a TrainStep, its captured hipGraphs - untouched.
 
     def engine(self):
         dev = next(self.parameters()).device

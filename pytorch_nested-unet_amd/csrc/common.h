@@ -1,6 +1,7 @@
 // common.h — shared device/host helpers for libnunet (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -45,13 +46,24 @@ enum {
 };
 extern thread_local bool g_prof_on;
 extern thread_local int g_prof_alg_cin;  // >0: algorithmic Cin of the next conv/wgrad (padded first layer)
-void nunet_prof_push(int cls, double flops, double bytes, hipStream_t st);
-void nunet_prof_pop(hipStream_t st);
+void nunet_prof_push(int cls, double flops, double bytes);
+void nunet_prof_pop();
+void nunet_prof_kernel_events(hipEvent_t* e0, hipEvent_t* e1);   // a fresh start/stop pair owned by the innermost open scope (null: none)
 struct ProfScope {
-  hipStream_t st; bool on;
-  ProfScope(int cls, double flops, double bytes, hipStream_t s) : st(s), on(g_prof_on) { if (on) nunet_prof_push(cls, flops, bytes, s); }
-  ~ProfScope() { if (on) nunet_prof_pop(st); }
+  bool on;
+  ProfScope(int cls, double flops, double bytes, hipStream_t) : on(g_prof_on) { if (on) nunet_prof_push(cls, flops, bytes); }
+  ~ProfScope() { if (on) nunet_prof_pop(); }
 };
+// Every kernel launch goes through this. Timing off: plain hipLaunchKernelGGL. Timing on (bench.py's roofline leg):
+// hipExtLaunchKernelGGL with a start/stop event pair, which carries the DISPATCH's own begin/end timestamps (what
+// rocprofv3 --kernel-trace reports) - events recorded around a launch as separate stream markers add ~5 us to a 15 us kernel.
+#define NUNET_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                    \
+  do {                                                                                                          \
+    hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                                  \
+    if (g_prof_on) nunet_prof_kernel_events(&pe0_, &pe1_);                                                      \
+    if (pe0_) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, pe0_, pe1_, 0, __VA_ARGS__);            \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                   \
+  } while (0)
 
 // zero-fill by a kernel on the caller's stream. hipMemsetAsync is NOT used anywhere:
 // captured into a hipGraph its memset node ran unordered w.r.t. the neighbouring kernel

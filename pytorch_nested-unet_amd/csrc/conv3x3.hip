@@ -746,9 +746,9 @@ TileGeom nunet_choose_tile(int N, int H, int W, int BM, int HPMAX) {
 template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR>
 static void launch_conv_lt(int lt, unsigned grid, size_t dyn, hipStream_t st, const ConvP& p) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
-  if (lt == 1) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 1>), dim3(grid), dim3(C::NT), dyn, st, p);
-  else if (lt == 2) hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 2>), dim3(grid), dim3(C::NT), dyn, st, p);
-  else hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 0>), dim3(grid), dim3(C::NT), dyn, st, p);
+  if (lt == 1) NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 1>), dim3(grid), dim3(C::NT), dyn, st, p);
+  else if (lt == 2) NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 2>), dim3(grid), dim3(C::NT), dyn, st, p);
+  else NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 0>), dim3(grid), dim3(C::NT), dyn, st, p);
 }
 
 template <typename T, int WM, int WN, int SM, int SN>
@@ -779,7 +779,9 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.S = 1; p.slabs = nullptr; p.slab_stride = 0;
   p.nch0 = p.C0 / C::KC;
   p.nch = p.nch0 + p.C1 / C::KC;
-  if (d->splitk_ws && items <= 100 && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
+  static int sk_max_items = -1;
+  if (sk_max_items < 0) { const char* e = getenv("NUNET_SK_MAXITEMS"); sk_max_items = e ? atoi(e) : 100; }
+  if (d->splitk_ws && items <= sk_max_items && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
     int S = (int)((320 + items - 1) / items);
     if (S > p.nch / 2) S = p.nch / 2;
     const long long need = (long long)S * d->N * d->H * d->W * p.Cout;
@@ -815,8 +817,8 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
     const int blk = G * (256 / G);
     long long fg = (f.npix + (blk / G) - 1) / (blk / G);
     if (fg > 1024) fg = 1024;
-    if (bnr) hipLaunchKernelGGL((splitk_finalize_kernel<T, true>), dim3((unsigned)fg), dim3(blk), 0, st, f);
-    else hipLaunchKernelGGL((splitk_finalize_kernel<T, false>), dim3((unsigned)fg), dim3(blk), 0, st, f);
+    if (bnr) NUNET_LAUNCH((splitk_finalize_kernel<T, true>), dim3((unsigned)fg), dim3(blk), 0, st, f);
+    else NUNET_LAUNCH((splitk_finalize_kernel<T, false>), dim3((unsigned)fg), dim3(blk), 0, st, f);
     return nunet_check_launch("conv3x3 (K-split)");
   }
   if (bnr) launch_conv_lt<T, WM, WN, SM, SN, false, true>(lt, (unsigned)grid, dyn, st, p);
@@ -826,7 +828,21 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
 
 template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream_t st) {
   const int cout = d->D0 + d->D1;
-  // Cout multiple of 64: 128 pixels x 64 channels per workgroup (2 x 2 waves of 64 x 32); otherwise 256 x 32
+  static int small_mode = -1;
+  if (small_mode < 0) { const char* e = getenv("NUNET_CONV_SMALL"); small_mode = e ? atoi(e) : 2; }
+  // Tile choice (measured per layer on MI355X, tools/conv_layers.py): the standard tiles are 128 pixels x 64 channels
+  // (Cout multiple of 64: 2 x 2 waves of 64 x 32) or 256 x 32. They leave a deep level (few pixels) with fewer work
+  // items than the chip has CUs; there the 128 x 32 tile (4 workgroups per CU, twice the items) wins by up to 2x and
+  // needs no K-split. It also wins for the plain / BN-forward Cout = 32 convs of the first level (one wave per SIMD
+  // with the 256-pixel tile). With the BN-backward input transform the small tile loses: every Cout tile repeats the
+  // transform of its input tile.
+  bool small = small_mode == 1;
+  if (small_mode == 2) {
+    const long px = (long)d->N * d->H * d->W;
+    const long items_std = cout % 64 == 0 ? ceil_div64(px, 128) * (cout / 64) : ceil_div64(px, 256) * (cout / 32);
+    small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD);
+  }
+  if (small) return launch_conv_cfg<T, 4, 1, 1, 1>(d, st);                              // 128 pixels x 32 channels
   if (cout % 64 == 0) return launch_conv_cfg<T, 2, 2, 2, 1>(d, st);
   return launch_conv_cfg<T, 4, 1, 2, 1>(d, st);
 }
@@ -1144,8 +1160,8 @@ template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStre
   const long grid = wgrad_setup<T>(d, p);
   double fl, by; wgrad_prof<T>(d, p, fl, by);
   ProfScope ps(p.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fl, by, st);
-  if (p.SH) hipLaunchKernelGGL((wgrad_kernel<T, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
-  else hipLaunchKernelGGL((wgrad_kernel<T, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  if (p.SH) NUNET_LAUNCH((wgrad_kernel<T, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  else NUNET_LAUNCH((wgrad_kernel<T, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
   return nunet_check_launch("wgrad3x3");
 }
 
@@ -1161,8 +1177,8 @@ template <typename T> static int launch_wgrad_pair(const WgPairArgs* w, hipStrea
     int rc = launch_wgrad<T>(w->a, st);
     return rc ? rc : launch_wgrad<T>(w->b, st);
   }
-  if (pa.SH) hipLaunchKernelGGL((wgrad_pair_kernel<T, true>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
-  else hipLaunchKernelGGL((wgrad_pair_kernel<T, false>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
+  if (pa.SH) NUNET_LAUNCH((wgrad_pair_kernel<T, true>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
+  else NUNET_LAUNCH((wgrad_pair_kernel<T, false>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
   return nunet_check_launch("wgrad3x3 (pair)");
 }
 
@@ -1208,6 +1224,6 @@ extern "C" int nunet_wgrad_reduce(const float* slabs, int64_t slab_stride, int32
   NUNET_REQUIRE(slabs && out && nslabs >= 1 && n > 0 && n % 4 == 0 && slab_stride % 4 == 0, "wgrad_reduce: bad args (n and slab_stride multiples of 4)");
   NUNET_REQUIRE(((uintptr_t)slabs & 15) == 0 && ((uintptr_t)out & 15) == 0, "wgrad_reduce: 16-byte alignment");
   long long g = (n / 4 + 255) / 256; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, slabs, (long long)slab_stride, nslabs, out, (long long)(n / 4), accumulate);
+  NUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, slabs, (long long)slab_stride, nslabs, out, (long long)(n / 4), accumulate);
   return nunet_check_launch("wgrad_reduce");
 }

@@ -21,6 +21,16 @@ int nunet_check_launch(const char* what) {
     nunet_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
     return NUNET_ELAUNCH;
   }
+  // NUNET_TRACE_LAUNCH=1 (diagnostic, eager mode only): name every launch on stderr and wait for it, so that a
+  // faulting kernel is the last name printed
+  static int trace = -1;
+  if (trace < 0) { const char* t = getenv("NUNET_TRACE_LAUNCH"); trace = t ? atoi(t) : 0; }
+  if (trace) {
+    fprintf(stderr, "[nunet] %s ... ", what); fflush(stderr);
+    e = hipDeviceSynchronize();
+    fprintf(stderr, "%s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr);
+    if (e != hipSuccess) { nunet_set_error("%s: execution failed: %s", what, hipGetErrorString(e)); return NUNET_ELAUNCH; }
+  }
   return NUNET_OK;
 }
 extern "C" const char* nunet_last_error(void) { return g_err; }
@@ -42,7 +52,7 @@ int nunet_zero_async(void* p, size_t bytes, hipStream_t st) {
   NUNET_REQUIRE(((uintptr_t)p % 16) == 0 && bytes % 4 == 0, "zero: buffer must be 16-byte aligned, size a multiple of 4");
   const size_t n16 = bytes / 16;
   const int ntail = (int)((bytes % 16) / 4);
-  hipLaunchKernelGGL(zero_kernel, dim3(grid_for((int64_t)n16, 256 * 4, 2048)), dim3(256), 0, st, (u32x4*)p, n16,
+  NUNET_LAUNCH(zero_kernel, dim3(grid_for((int64_t)n16, 256 * 4, 2048)), dim3(256), 0, st, (u32x4*)p, n16,
                      (uint32_t*)((char*)p + n16 * 16), ntail);
   return nunet_check_launch("zero");
 }
@@ -77,7 +87,7 @@ template <typename T> static int launch_nchw_to_nhwc(const float* x, int N, int 
   NUNET_REQUIRE(hw * groups < (1ll << 31), "nchw_to_nhwc: image too large");
   const int64_t total = (int64_t)N * H * W * cpad;
   ProfScope ps(PC_LAYOUT, 0, (double)total * sizeof(T) + (double)N * C * H * W * 4, st);
-  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(hw * groups, 256, 1024), N), dim3(256), 0, st, x, C, (int)hw, (T*)y, cpad, gshift);
+  NUNET_LAUNCH((nchw_to_nhwc_kernel<T>), dim3(grid_for(hw * groups, 256, 1024), N), dim3(256), 0, st, x, C, (int)hw, (T*)y, cpad, gshift);
   return nunet_check_launch("nchw_to_nhwc");
 }
 extern "C" int nunet_nchw_to_nhwc(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t dtype, void* y, int32_t cpad, nunet_stream_t s) {
@@ -123,7 +133,7 @@ extern "C" int nunet_preprocess_u8(const uint8_t* u8_nhwc, int32_t N, int32_t H,
   const int64_t total = (int64_t)N * C * H * W;
   hipStream_t st = (hipStream_t)s;
   ProfScope ps(PC_LAYOUT, 0, (double)total * 5, st);
-  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(total, 256 * 4, 2048)), dim3(256), 0, st, u8_nhwc, N, H, W, C, mean, stdv, aug, post_scale, out_nchw);
+  NUNET_LAUNCH(preprocess_u8_kernel, dim3(grid_for(total, 256 * 4, 2048)), dim3(256), 0, st, u8_nhwc, N, H, W, C, mean, stdv, aug, post_scale, out_nchw);
   return nunet_check_launch("preprocess_u8");
 }
 
@@ -261,10 +271,10 @@ template <typename T> static int launch_bn_fwd(const nunet_bn_fwd_desc* d, hipSt
   ProfScope ps(PC_BN_FWD, 0, (double)d->N * d->H * d->W * d->C * sizeof(T) * (d->pooled ? 2.25 : 2.0), st);
   if (d->pooled) {
     const int64_t nq = (int64_t)d->N * (d->H / 2) * (d->W / 2);
-    hipLaunchKernelGGL((bn_relu_fwd_kernel<T, true>), dim3(grid_for(nq, ppb * 2, 2048)), dim3(256), 0, st, p);
+    NUNET_LAUNCH((bn_relu_fwd_kernel<T, true>), dim3(grid_for(nq, ppb * 2, 2048)), dim3(256), 0, st, p);
   } else {
     const int64_t np = (int64_t)d->N * d->H * d->W;
-    hipLaunchKernelGGL((bn_relu_fwd_kernel<T, false>), dim3(grid_for(np, ppb * 4, 2048)), dim3(256), 0, st, p);
+    NUNET_LAUNCH((bn_relu_fwd_kernel<T, false>), dim3(grid_for(np, ppb * 4, 2048)), dim3(256), 0, st, p);
   }
   return nunet_check_launch("bn_relu_fwd");
 }
@@ -414,7 +424,7 @@ template <typename T, bool APPLY> static int launch_bn_bwd_t(const nunet_bn_bwd_
   // fewer, fatter blocks: each block ends with 2C global atomics
   ProfScope ps(APPLY ? PC_BN_BWD_APPLY : PC_BN_BWD_REDUCE, 0, (double)np * d->C * sizeof(T) * (APPLY ? 3.0 : 2.0), st);
   // fat blocks: every block ends with C (2C) same-address global atomics
-  hipLaunchKernelGGL((bn_relu_bwd_kernel<T, APPLY>), dim3(grid_for(np, (256 / G) * bn_bwd_ipb(), bn_bwd_cap(APPLY))), dim3(256), 0, st, p);
+  NUNET_LAUNCH((bn_relu_bwd_kernel<T, APPLY>), dim3(grid_for(np, (256 / G) * bn_bwd_ipb(), bn_bwd_cap(APPLY))), dim3(256), 0, st, p);
   return nunet_check_launch(APPLY ? "bn_relu_bwd_apply" : "bn_relu_bwd_reduce");
 }
 template <typename T> static int launch_bn_bwd_reduce(const nunet_bn_bwd_desc* d, hipStream_t st) { return launch_bn_bwd_t<T, false>(d, st); }
@@ -505,13 +515,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 template <typename T> static int launch_maxpool_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
   ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * 1.25, st);
-  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
+  NUNET_LAUNCH((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
   return nunet_check_launch("maxpool_fwd");
 }
 template <typename T> static int launch_maxpool_bwd(int N, int H, int W, int C, const void* x, int PX, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
   ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * (acc ? 3.25 : 2.25), st);
-  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
+  NUNET_LAUNCH((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
   return nunet_check_launch("maxpool_bwd");
 }
 static int ew_check(const char* what, int dtype, int N, int H, int W, int C, int p0, int p1) {
@@ -648,13 +658,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 template <typename T> static int launch_up_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * 4 * H * W * (C / Tr<T>::EPV);
   ProfScope ps(PC_UP_FWD, 0, (double)N * H * W * C * sizeof(T) * 5.0, st);
-  hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, 2 * W, 2 * H));
+  NUNET_LAUNCH((upsample_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, 2 * W, 2 * H));
   return nunet_check_launch("upsample_fwd");
 }
 template <typename T> static int launch_up_bwd(int N, int H, int W, int C, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
   const int64_t total = (int64_t)N * H * W * (C / Tr<T>::EPV);
   ProfScope ps(PC_UP_BWD, 0, (double)N * H * W * C * sizeof(T) * (acc ? 6.0 : 5.0), st);
-  hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H));
+  NUNET_LAUNCH((upsample_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H));
   return nunet_check_launch("upsample_bwd");
 }
 extern "C" int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s) {
@@ -794,13 +804,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
 }
 template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* b, float* logits, hipStream_t st) {
   ProfScope ps(PC_HEAD, 2.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) + K * 4), st);
-  hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 256)), dim3(256), 0, st, (const T*)x, PX, w, b, logits, N, H, W, C, K);
+  NUNET_LAUNCH((head_fwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 256)), dim3(256), 0, st, (const T*)x, PX, w, b, logits, N, H, W, C, K);
   return nunet_check_launch("head_fwd");
 }
 template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw_slabs, int nslabs, hipStream_t st) {
   ProfScope ps(PC_HEAD, 4.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) * (acc ? 3 : 2) + K * 4), st);
   const dim3 grid(nslabs), blk(256);
-#define NUNET_HB(KT) hipLaunchKernelGGL((head_bwd_kernel<T, KT>), grid, blk, 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw_slabs, N, H, W, C, K)
+#define NUNET_HB(KT) NUNET_LAUNCH((head_bwd_kernel<T, KT>), grid, blk, 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw_slabs, N, H, W, C, K)
   if (K == 1) NUNET_HB(1); else if (K == 2) NUNET_HB(2); else if (K == 4) NUNET_HB(4); else NUNET_HB(0);
 #undef NUNET_HB
   return nunet_check_launch("head_bwd");
@@ -885,15 +895,15 @@ extern "C" int nunet_bce_dice_fwd(const float* logits, const float* target, int3
   hipStream_t st = (hipStream_t)s;
   const int gx = grid_for(per, 256 * 4, BCE_GX);
   ProfScope ps(PC_LOSS, 0, (double)N * per * 8, st);
-  hipLaunchKernelGGL(bce_dice_partial_kernel, dim3(gx, N), dim3(256), 0, st, logits, target, per, ws, N);
-  hipLaunchKernelGGL(bce_dice_final_kernel, dim3(1), dim3(64), 0, st, ws, N, gx, per, loss);
+  NUNET_LAUNCH(bce_dice_partial_kernel, dim3(gx, N), dim3(256), 0, st, logits, target, per, ws, N);
+  NUNET_LAUNCH(bce_dice_final_kernel, dim3(1), dim3(64), 0, st, ws, N, gx, per, loss);
   return nunet_check_launch("bce_dice_fwd");
 }
 extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per, const float* ws, const float* gscale, float* dlogits, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && dlogits && N > 0 && per > 0, "bce_dice_bwd: bad args");
   const int gx = grid_for(per, 256 * 4, 64);
   ProfScope ps(PC_LOSS, 0, (double)N * per * 12, (hipStream_t)s);
-  hipLaunchKernelGGL(bce_dice_bwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)s, logits, target, per, ws, gscale, dlogits, N);
+  NUNET_LAUNCH(bce_dice_bwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)s, logits, target, per, ws, gscale, dlogits, N);
   return nunet_check_launch("bce_dice_bwd");
 }
 
@@ -1015,8 +1025,8 @@ extern "C" int nunet_loss_step(const float* logits, const float* target, int32_t
   hipStream_t st = (hipStream_t)s;
   const int gx = grid_for(per, 256, LOSS_GX);     // one element per thread up to 128x128 images: the step waits on this pair of launches
   ProfScope ps(PC_LOSS, 0, (double)N * per * heads * 16, st);
-  hipLaunchKernelGGL(loss_step_partial_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, N, heads);
-  hipLaunchKernelGGL(loss_step_bwd_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, gx, N, heads, dlogits, loss_out, meters);
+  NUNET_LAUNCH(loss_step_partial_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, N, heads);
+  NUNET_LAUNCH(loss_step_bwd_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, gx, N, heads, dlogits, loss_out, meters);
   return nunet_check_launch("loss_step");
 }
 
@@ -1040,7 +1050,7 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict
 extern "C" int nunet_iou_counts(const float* logits, const float* target, int64_t n, unsigned long long* counts, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && counts && n > 0, "iou_counts: bad args");
   ProfScope ps(PC_LOSS, 0, (double)n * 8, (hipStream_t)s);
-  hipLaunchKernelGGL(iou_counts_kernel, dim3(grid_for(n, 256 * 4, 256)), dim3(256), 0, (hipStream_t)s, logits, target, n, counts);
+  NUNET_LAUNCH(iou_counts_kernel, dim3(grid_for(n, 256 * 4, 256)), dim3(256), 0, (hipStream_t)s, logits, target, n, counts);
   return nunet_check_launch("iou_counts");
 }
 
@@ -1068,7 +1078,7 @@ __global__ __launch_bounds__(256) void sigmoid_u8_kernel(const float* __restrict
 extern "C" int nunet_sigmoid_u8(const float* logits, uint8_t* out, int64_t n, nunet_stream_t s) {
   NUNET_REQUIRE(logits && out && n > 0, "sigmoid_u8: bad args");
   NUNET_REQUIRE(((uintptr_t)logits & 15) == 0 && ((uintptr_t)out & 3) == 0, "sigmoid_u8: logits must be 16-byte and out 4-byte aligned");
-  hipLaunchKernelGGL(sigmoid_u8_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)s, logits, out, n);
+  NUNET_LAUNCH(sigmoid_u8_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)s, logits, out, n);
   return nunet_check_launch("sigmoid_u8");
 }
 
@@ -1091,6 +1101,6 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 extern "C" int nunet_sgd_step(float* p, const float* g, float* mom, int64_t n, const float* lr_dev, float momentum, float weight_decay, int32_t nesterov, int32_t first, float grad_scale, nunet_stream_t s) {
   NUNET_REQUIRE(p && g && lr_dev && n > 0 && (momentum == 0.f || mom), "sgd_step: bad args");
   ProfScope ps(PC_SGD, 0, (double)n * 20, (hipStream_t)s);
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, (hipStream_t)s, p, g, mom, n, lr_dev, momentum, weight_decay, nesterov, first, grad_scale);
+  NUNET_LAUNCH(sgd_kernel, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, (hipStream_t)s, p, g, mom, n, lr_dev, momentum, weight_decay, nesterov, first, grad_scale);
   return nunet_check_launch("sgd_step");
 }

@@ -281,8 +281,8 @@ extern "C" int nunet_lovasz_hinge_fwd(const float* logits, const float* target, 
     int np2 = lovasz_np2(per_image);
     if (np2 < 2 * LOVASZ_NT) np2 = 2 * LOVASZ_NT;      // every thread owns at least one compare pair / scan run
     const size_t lds = (size_t)np2 * 8;
-    hipLaunchKernelGGL(lovasz_hinge_kernel, dim3(N), dim3(LOVASZ_NT), lds, st, logits, target, (int)per_image, np2, dlogits_unit, ws, 1.f / (float)N);
-    hipLaunchKernelGGL(lovasz_mean_kernel, dim3(1), dim3(64), 0, st, ws, N, loss);
+    NUNET_LAUNCH(lovasz_hinge_kernel, dim3(N), dim3(LOVASZ_NT), lds, st, logits, target, (int)per_image, np2, dlogits_unit, ws, 1.f / (float)N);
+    NUNET_LAUNCH(lovasz_mean_kernel, dim3(1), dim3(64), 0, st, ws, N, loss);
     return nunet_check_launch("lovasz_hinge_fwd");
   }
   const int np2 = lovasz_np2(per_image), nch = np2 / LV_CHUNK;
@@ -290,22 +290,22 @@ extern "C" int nunet_lovasz_hinge_fwd(const float* logits, const float* target, 
   float* csum = reinterpret_cast<float*>(keys + (size_t)N * np2);
   float* part = csum + (size_t)N * nch;
   const unsigned gx = (unsigned)((np2 / 2 + 255) / 256 > 1024 ? 1024 : (np2 / 2 + 255) / 256);
-  hipLaunchKernelGGL(lv_keys_kernel, dim3(gx, N), dim3(256), 0, st, logits, target, (int)per_image, np2, keys);
-  hipLaunchKernelGGL(lv_local_kernel, dim3(nch, N), dim3(LOVASZ_NT), LV_CHUNK * 8, st, keys, np2, 1, 0);
+  NUNET_LAUNCH(lv_keys_kernel, dim3(gx, N), dim3(256), 0, st, logits, target, (int)per_image, np2, keys);
+  NUNET_LAUNCH(lv_local_kernel, dim3(nch, N), dim3(LOVASZ_NT), LV_CHUNK * 8, st, keys, np2, 1, 0);
   for (int k = 2 * LV_CHUNK; k <= np2; k <<= 1) {
     for (int j = k >> 1; j >= LV_CHUNK; j >>= 1)
-      hipLaunchKernelGGL(lv_global_kernel, dim3(gx, N), dim3(256), 0, st, keys, np2, k, j);
-    hipLaunchKernelGGL(lv_local_kernel, dim3(nch, N), dim3(LOVASZ_NT), LV_CHUNK * 8, st, keys, np2, 0, k);
+      NUNET_LAUNCH(lv_global_kernel, dim3(gx, N), dim3(256), 0, st, keys, np2, k, j);
+    NUNET_LAUNCH(lv_local_kernel, dim3(nch, N), dim3(LOVASZ_NT), LV_CHUNK * 8, st, keys, np2, 0, k);
   }
-  hipLaunchKernelGGL(lv_chunksum_kernel, dim3(nch, N), dim3(LOVASZ_NT), 0, st, keys, np2, csum);
-  hipLaunchKernelGGL(lv_final_kernel, dim3(nch, N), dim3(LOVASZ_NT), 0, st, keys, (int)per_image, np2, csum, dlogits_unit, part, 1.f / (float)N);
-  hipLaunchKernelGGL(lv_mean_kernel, dim3(1), dim3(64), 0, st, part, N * nch, N, loss);
+  NUNET_LAUNCH(lv_chunksum_kernel, dim3(nch, N), dim3(LOVASZ_NT), 0, st, keys, np2, csum);
+  NUNET_LAUNCH(lv_final_kernel, dim3(nch, N), dim3(LOVASZ_NT), 0, st, keys, (int)per_image, np2, csum, dlogits_unit, part, 1.f / (float)N);
+  NUNET_LAUNCH(lv_mean_kernel, dim3(1), dim3(64), 0, st, part, N * nch, N, loss);
   return nunet_check_launch("lovasz_hinge_fwd (global sort)");
 }
 extern "C" int nunet_lovasz_hinge_bwd(const float* dlogits_unit, const float* gscale, int64_t n, float* dlogits, nunet_stream_t s) {
   NUNET_REQUIRE(dlogits_unit && dlogits && n > 0, "lovasz_hinge_bwd: bad args");
   int64_t g = (n + 1023) / 1024;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, dlogits_unit, gscale, dlogits, n);
+  NUNET_LAUNCH(scale_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, dlogits_unit, gscale, dlogits, n);
   return nunet_check_launch("lovasz_hinge_bwd");
 }

@@ -386,7 +386,7 @@ template <typename T> static int launch_pack(const float* params, void* arena_t,
   double pb = 0;
   for (int i = 0; i < tab.n; ++i) pb += 9.0 * tab.e[i].cout * tab.e[i].cin * (4 + (tab.e[i].wd >= 0 ? 2 : 1) * sizeof(T));
   ProfScope ps(PC_PACK, 0, pb, st);
-  hipLaunchKernelGGL((pack_kernel<T>), dim3(nt), dim3(256), 0, st, params, (T*)arena_t, tab);
+  NUNET_LAUNCH((pack_kernel<T>), dim3(nt), dim3(256), 0, st, params, (T*)arena_t, tab);
   return nunet_check_launch("pack_weights");
 }
 
@@ -414,7 +414,7 @@ extern "C" int nunet_unpack_wgrad(const float* dw, int32_t cout, int32_t cin, in
   int gx = (int)ceil_div64(9LL * cout * cin, 256 * 4);
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(unpack_kernel, dim3(gx, 1), dim3(256), 0, (hipStream_t)s, dw, g, tab);
+  NUNET_LAUNCH(unpack_kernel, dim3(gx, 1), dim3(256), 0, (hipStream_t)s, dw, g, tab);
   return nunet_check_launch("unpack_wgrad");
 }
 
@@ -768,7 +768,7 @@ struct Sched {
     if (!rt->stamps) return;
     std::vector<std::string>& lab = rt->stamp_labels[pass];
     if ((int)lab.size() >= STAMP_CAP) return;
-    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, rt->stamps + (size_t)pass * STAMP_CAP + lab.size());
+    NUNET_LAUNCH(stamp_kernel, dim3(1), dim3(1), 0, st, rt->stamps + (size_t)pass * STAMP_CAP + lab.size());
     char b[48]; snprintf(b, sizeof(b), "L%d %s", lane, cur_name);
     lab.push_back(b);
   }
@@ -1134,9 +1134,9 @@ extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, 
   ProfScope ps(PC_SGD, 0, (double)P->nparams * (grads ? 28.0 : 24.0), st);
   void* wp = AB(arena, P->off_wpack);
   const dim3 grid(nt + nheads), blk(512);
-  if (P->cfg.dtype == NUNET_F32) hipLaunchKernelGGL((update_kernel<float>), grid, blk, 0, st, u, (float*)wp, tab, P->utab);
-  else if (P->cfg.dtype == NUNET_BF16) hipLaunchKernelGGL((update_kernel<bf16_t>), grid, blk, 0, st, u, (bf16_t*)wp, tab, P->utab);
-  else hipLaunchKernelGGL((update_kernel<f16_t>), grid, blk, 0, st, u, (f16_t*)wp, tab, P->utab);
+  if (P->cfg.dtype == NUNET_F32) NUNET_LAUNCH((update_kernel<float>), grid, blk, 0, st, u, (float*)wp, tab, P->utab);
+  else if (P->cfg.dtype == NUNET_BF16) NUNET_LAUNCH((update_kernel<bf16_t>), grid, blk, 0, st, u, (bf16_t*)wp, tab, P->utab);
+  else NUNET_LAUNCH((update_kernel<f16_t>), grid, blk, 0, st, u, (f16_t*)wp, tab, P->utab);
   return nunet_check_launch("plan_update");
 }
 
@@ -1246,7 +1246,7 @@ extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, voi
   int nt = 0;
   for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
   tab.tile0[tab.n] = nt; tab.ntiles = nt;
-  hipLaunchKernelGGL(unpack_sgd_tiled_kernel, dim3(nt + P->utab.n), dim3(256), 0, st, u, tab, P->utab);
+  NUNET_LAUNCH(unpack_sgd_tiled_kernel, dim3(nt + P->utab.n), dim3(256), 0, st, u, tab, P->utab);
   return nunet_check_launch("plan_sgd");
 }
 
@@ -1307,7 +1307,7 @@ static int launch_reduce(nunet_plan* P, void* arena, int k_lo, int k_hi, hipStre
     }
   if (tab.n == 0) return NUNET_OK;
   ProfScope ps(PC_UNPACK, 0, bytes, st);
-  hipLaunchKernelGGL(reduce_kernel, dim3(tab.nblocks), dim3(256), 0, st, (const float*)AB(arena, P->off_slab), (float*)AB(arena, P->off_gs), tab);
+  NUNET_LAUNCH(reduce_kernel, dim3(tab.nblocks), dim3(256), 0, st, (const float*)AB(arena, P->off_slab), (float*)AB(arena, P->off_gs), tab);
   return nunet_check_launch("wgrad slab reduce");
 }
 
@@ -1344,6 +1344,10 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     written[0][h.slot] = true;
   }
   const bool b0_inside = (phases & 3) == 3 && rt_of(P)->b0_enabled && !P->cfg.unet;   // bucket 0 signalled from inside the pass
+  // NUNET_DEBUG_SPIN_US (tests only): a spin kernel of that many microseconds heads phase 2 on the chain lane, so that
+  // "bucket 0 is complete well before the pass ends" can be asserted with a margin (tests/test_dist_gpu.py)
+  static int spin_us = -1;
+  if (spin_us < 0) { const char* e = getenv("NUNET_DEBUG_SPIN_US"); spin_us = e ? atoi(e) : 0; }
 
   for (int k = k_hi; k >= k_lo && rc == NUNET_OK; --k) {
     const Node& n = P->exec[k];
@@ -1351,6 +1355,11 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     const int lane = lane_of(P, n), wlane = 5 + lane, rb = R_BLK + k * B_STRIDE, rl = R_LVL + k * L_STRIDE;
     const int rsk = P->sk_floats[i] > 0 ? R_SK + i : -1;
     if (!written[i][n.out_slot]) { nunet_set_error("plan_backward: internal: grad of x%d_%d never produced", n.i, n.j); rc = NUNET_EINVAL; break; }
+    if (spin_us > 0 && k == k_split - 1 && (phases & 2)) {
+      const int us = spin_us;
+      S.name("spin");
+      S.add(lane, 0, 0.f, {R_GX + i * 5 + n.out_slot}, {R_GX + i * 5 + n.out_slot}, [=](hipStream_t ls) { return nunet_debug_spin(us, 1, (nunet_stream_t)ls); });
+    }
     const ConvL& L1 = n.c1; const ConvL& L2 = n.c2;
     char* const dy2 = AB(arena, P->off_dy[k][0]); char* const dy1 = AB(arena, P->off_dy[k][1]);
     char* const da1 = AB(arena, P->off_da1[k]);
@@ -1505,7 +1514,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   int nt = 0;
   for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); }
   tab.tile0[tab.n] = nt; tab.ntiles = nt;
-  hipLaunchKernelGGL(unpack_tiled_kernel, dim3(P->ptab.ntiles + P->utab.n), dim3(256), 0, st, gsr, grads, P->ptab, P->utab);
+  NUNET_LAUNCH(unpack_tiled_kernel, dim3(P->ptab.ntiles + P->utab.n), dim3(256), 0, st, gsr, grads, P->ptab, P->utab);
   return nunet_check_launch("unpack_grads");
 }
 

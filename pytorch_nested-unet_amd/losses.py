@@ -18,7 +18,7 @@ class _BCEDiceFn(torch.autograd.Function):
         n = logits.size(0)
         per = logits.numel() // n
         lib = L.lib()
-        ws = torch.empty(3 * n + 4, dtype=torch.float32, device=logits.device)   # 16-byte aligned by the allocator
+        ws = torch.empty(lib.nunet_bce_dice_ws_bytes(n) // 4 + 4, dtype=torch.float32, device=logits.device)   # the library states the size
         loss = torch.empty(1, dtype=torch.float32, device=logits.device)
         L.check(lib.nunet_bce_dice_fwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.ptr(loss), L.stream()),
                 "nunet_bce_dice_fwd")

@@ -34,6 +34,20 @@ def allreduce_flat_(flat, group=None):
     return flat
 
 
+def broadcast_flat_(flat, src=0, group=None):
+    """Overwrite `flat` on every rank with rank `src`'s copy (initial state / checkpoint policy). Same host round
+    trip as allreduce_flat_ under gloo."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return flat
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
 def shard_seed(base_seed, rank, step, world):
     """Seed of the synthetic shard rank `rank` consumes at `step`: disjoint across ranks."""
     return base_seed + step * world + rank

@@ -5,9 +5,17 @@ replay per step, with no host synchronisation: loss and IoU counts stay on the
 device and are read back only when the caller asks (AverageMeter semantics of
 utils.py:17-33 are kept by `epoch_stats`).
 
-Data parallel (new capability): one process per GPU, local
-BatchNorm statistics (plain nn.BatchNorm2d semantics, archs1.py:19,21), one
-gradient all-reduce per step over RCCL, buckets in gradient-ready order.
+Data parallel (new capability): one process per GPU, one gradient
+all-reduce per step over RCCL, buckets in gradient-ready order. Replica state:
+  * parameters, momentum and BatchNorm buffers are broadcast from rank 0 when the
+    TrainStep is built (what DistributedDataParallel does at construction), so ranks
+    that initialised differently or loaded a checkpoint on rank 0 only start identical;
+  * BatchNorm batch statistics stay LOCAL to a replica (plain nn.BatchNorm2d semantics,
+    archs1.py:19,21: every replica normalises over its own 16 images, exactly like the
+    single-GPU reference step); the running statistics therefore drift apart between
+    ranks, and the policy is "rank 0's buffers are the model's": sync_bn_buffers()
+    broadcasts them before validation / checkpointing (train.py does);
+  * p.grad holds the rank-MEAN gradient in every step layout (as DDP leaves it).
 """
 import math
 import os
@@ -16,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
-from .parallel import allreduce_flat_
+from .parallel import allreduce_flat_, broadcast_flat_
 
 
 class TrainStep:
@@ -54,13 +62,18 @@ class TrainStep:
         # so that bucket 0's exchange runs beside phase 2. Measured on one MI355X (single-rank RCCL group,
         # tools/dp_probe.py): the cut costs 500 us per step (phase 1 is the anti-diagonal's dependency chain with nothing
         # beside it, 2.71 ms vs 2.18 ms) - more than the 36.7 MB exchange it hides is expected to take on >= 4 GPUs.
-        self.dp_mode = int(os.environ.get("NUNET_DP_MODE", "1"))
+        # NUNET_DP_MODE unset / "auto": with more than one rank, capture() times layouts 1 and 2 on the real exchange and
+        # keeps the faster (the decision is all-reduced, so every rank takes the same one); one rank: layout 1.
+        mode = os.environ.get("NUNET_DP_MODE", "auto")
+        self.dp_auto = mode == "auto" and self.dp
+        self.dp_mode = 1 if mode == "auto" else int(mode)
+        self.dp_choice = None        # (ms layout 1, ms layout 2) when the layout was chosen by measurement
         self.use_graph = use_graph
         # optimiser step layout: 0 = unpack, SGD, (next forward's) pack as three streaming launches; 2 (default) = unpack
         # with the SGD step as its epilogue (nunet_plan_sgd, 46 us against 59 us for the pair); 1 = one tile kernel that
         # also repacks the weights (nunet_plan_update). The flat OIHW gradients (p.grad views) are materialised with
-        # keep_grads=True in the fused layouts, where they hold the rank-MEAN gradient (grad_scale = 1/world applied, as
-        # DistributedDataParallel leaves p.grad); layout 0 leaves the rank-SUM there and scales inside the SGD kernel.
+        # keep_grads=True in the fused layouts; in every layout they hold the rank-MEAN gradient (as
+        # DistributedDataParallel leaves p.grad).
         self.fused_update = int(os.environ.get("NUNET_FUSED_UPDATE", "2")) if fused_update is None else int(fused_update)   
         self.keep_grads = keep_grads
         self._packed = False          # the arena's packed weights match the fp32 parameters
@@ -69,11 +82,37 @@ class TrainStep:
         self.g_opt = None
         self._buckets = self._grad_scratch() if self.dp else None
         self._b0_armed = False
+        self._comm = torch.cuda.Stream() if self.dp else None
         if self.dp and self.dp_mode == 2:
-            self._b0_armed = L.lib().nunet_plan_bucket0_enable(self.pl.handle, 1) == 1
-            self._comm = torch.cuda.Stream()
+            self._arm_bucket0(True)
         for p, off in zip(self.eng.module_params, self.eng.param_off):
             p.grad = self.eng.flat_grads[off:off + p.numel()].view(p.shape)
+        if self.world > 1:
+            self.broadcast_state()
+
+    def _arm_bucket0(self, on):
+        self._b0_armed = L.lib().nunet_plan_bucket0_enable(self.pl.handle, 1 if on else 0) == 1
+
+    def broadcast_state(self, src=0):
+        """Rank `src`'s parameters, momentum and BatchNorm buffers become every rank's (construction time; also after
+        loading a checkpoint on one rank)."""
+        eng = self.eng
+        for t in (eng.flat_params, self.mom, eng.bnbuf):
+            broadcast_flat_(t, src, self.pg)
+        nbt = eng.nbt.to(torch.float64)          # (gloo / RCCL both take floating tensors; counts are exact in fp64)
+        broadcast_flat_(nbt, src, self.pg)
+        eng.nbt.copy_(nbt.to(torch.int64))
+        self._packed = False
+
+    def sync_bn_buffers(self, src=0):
+        """BatchNorm running statistics policy under data parallel: rank `src`'s buffers are the model's. Call before
+        validating or saving a checkpoint (batch statistics, and hence the buffers, are per replica during training)."""
+        if self.world > 1:
+            eng = self.eng
+            broadcast_flat_(eng.bnbuf, src, self.pg)
+            nbt = eng.nbt.to(torch.float64)
+            broadcast_flat_(nbt, src, self.pg)
+            eng.nbt.copy_(nbt.to(torch.int64))
 
     # -- pieces -------------------------------------------------------------------
     def _fwd_loss(self):
@@ -117,9 +156,11 @@ class TrainStep:
         if self.fused_update:
             return self._update()
         eng = self.eng
+        if self.world > 1:
+            eng.flat_grads.mul_(1.0 / self.world)      # p.grad = rank mean in every layout
         L.check(L.lib().nunet_sgd_step(L.ptr(eng.flat_params), L.ptr(eng.flat_grads), L.ptr(self.mom),
                                        eng.flat_params.numel(), L.ptr(self.lr), self.momentum, self.wd,
-                                       1 if self.nesterov else 0, 0, 1.0 / self.world, L.stream()), "sgd_step")
+                                       1 if self.nesterov else 0, 0, 1.0, L.stream()), "sgd_step")
 
     def _grad_scratch(self):
         """The plan's native-layout gradient scratch as two fp32 views in gradient-ready order."""
@@ -209,17 +250,16 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         if not self.dp:
-            # lane-faithful hipGraph (csrc/graph.hip): captured on a side stream, edge lists rewritten so
-            # that ROCm's node->stream assignment reproduces the plan's lanes, replayed on the caller's stream
+            # the whole step as ONE hipGraph (csrc/graph.hip), captured on a side stream, replayed on the caller's
             self.g_fb = _NativeGraph(s, lambda: (self._fwd_bwd(), self._opt()))
             iters = int(os.environ.get("NUNET_GRAPH_TUNE", "0"))
             if iters > 0:
                 self.tune_result = self.g_fb.tune(iters)
         else:
+            if self.dp_auto:
+                self._choose_layout(s)
             if self.dp_mode in (1, 2):
-                self.g_fb = _NativeGraph(s, lambda: (self._fwd_loss(), self._bwd(3)))
-                self.g_b2 = None
-                self.g_opt = _NativeGraph(s, lambda: (None if self.fused_update else self._bwd(4), self._opt()))
+                self._capture_one_pass(s)
         if self.dp and self.dp_mode not in (1, 2):
             self.g_fb = torch.cuda.CUDAGraph()          # forward + loss + backward phase 1
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):   # (the RCCL watchdog thread polls events meanwhile)
@@ -240,9 +280,52 @@ class TrainStep:
         self.steps = steps0
         self.sync_weights()            # the restored parameters, repacked
 
+    def _capture_one_pass(self, s):
+        """Layouts 1 and 2: forward + loss + the whole backward as one graph (layout 2: with the bucket-0 event recorded
+        inside it), the exchange between, unpack + SGD as a second graph."""
+        self._arm_bucket0(self.dp_mode == 2)
+        self.g_fb = _NativeGraph(s, lambda: (self._fwd_loss(), self._bwd(3)))
+        self.g_b2 = None
+        self.g_opt = _NativeGraph(s, lambda: (None if self.fused_update else self._bwd(4), self._opt()))
+
+    def _choose_layout(self, s, reps=8):
+        """Time layout 1 (one exchange after the pass) against layout 2 (bucket 0 exchanged beside the rest of the
+        backward pass) on the real process group and keep the faster. The caller restores the training state."""
+        times = []
+        for mode in (1, 2):
+            self.dp_mode = mode
+            self._capture_one_pass(s)
+            if mode == 2 and not self._b0_armed:
+                times.append(float("inf"))
+                continue
+            run = lambda: self._dp_step(self.g_fb.replay, None, self.g_opt.replay)
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / reps)
+        t = torch.tensor(times, dtype=torch.float64, device=self.eng.device)
+        t = torch.nan_to_num(t, posinf=1e30)
+        if dist.get_backend(self.pg) == "gloo":
+            h = t.cpu(); dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.pg); t = h
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)     # the slowest rank decides, identically everywhere
+        t = t.tolist()
+        self.dp_choice = (t[0], t[1])
+        self.dp_mode = 2 if t[1] < t[0] else 1
+        self.g_fb = self.g_opt = None
+
     def step(self, inp=None, target=None):
         """One training iteration. `inp`/`target` are device tensors (copied into the
         static graph inputs); None re-uses what is already staged."""
+        if self.model._engine is not self.eng or not self.eng.intact():
+            raise L.NunetError("the module's parameter arenas were re-homed (moved to another device / parameters replaced) "
+                               "after this TrainStep was built: its graphs would update orphaned memory. Build a new TrainStep.")
         if inp is not None:
             self.x.copy_(inp, non_blocking=True)
             self.t.copy_(target, non_blocking=True)

@@ -28,12 +28,18 @@ def _worker(rank, world, port, use_graph, dp_mode, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     synth = nunet_amd.synth
-    st = synth.closed_form_state(1, 3, False, True)
+    # rank 0 holds the closed-form state, rank 1 a different one (salt) with non-trivial BN buffers: the TrainStep
+    # broadcasts rank 0's parameters / momentum / BatchNorm buffers at construction, like DistributedDataParallel
+    st = synth.closed_form_state(1, 3, False, True) if rank == 0 else synth.closed_form_state(1, 3, False, False, salt=7)
     m = nunet_amd.archs.NestedUNet(1, 3, False)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
     m = m.cuda().train()
     ts = TrainStep(m, (2, 3, 32, 32), lr=1e-2, momentum=0.9, weight_decay=1e-4, use_graph=use_graph)
     assert ts.world == 2
+    ref0 = synth.closed_form_state(1, 3, False, True)
+    sd0 = m.state_dict()
+    for k in ("conv0_0.conv1.weight", "conv4_0.bn2.running_var", "conv2_1.bn1.num_batches_tracked", "final.bias"):
+        assert np.array_equal(sd0[k].cpu().numpy(), np.asarray(ref0[k])), k
     img, msk = synth.synth_batch(2, 32, 32, 3, 1, seed=500 + rank)
     x, t = torch.from_numpy(img).cuda(), torch.from_numpy(msk).cuda()
     if use_graph:
@@ -41,16 +47,18 @@ def _worker(rank, world, port, use_graph, dp_mode, q):
     ts.step(x, t)
     torch.cuda.synchronize()
     w = m.conv0_4.conv2.weight.detach().cpu().clone()
-    g = m.conv0_4.conv2.weight.grad.detach().cpu().clone()     # summed over ranks by the all-reduce
-    if ts.fused_update:
-        g = g * world          # the fused optimiser layouts leave the rank-MEAN gradient in p.grad (grad_scale applied)
+    g = m.conv0_4.conv2.weight.grad.detach().cpu().clone() * world     # p.grad is the rank MEAN in every layout
     ts.step(x, t)
     torch.cuda.synchronize()
-    q.put((rank, w.numpy(), g.numpy(), m.conv3_1.conv1.weight.detach().cpu().numpy(), ts.epoch_stats()))
+    # BatchNorm running statistics are per replica during training (different shards); the policy makes rank 0's the model's
+    rv_local = m.conv0_0.bn1.running_var.detach().cpu().numpy().copy()
+    ts.sync_bn_buffers()
+    rv_synced = m.conv0_0.bn1.running_var.detach().cpu().numpy().copy()
+    q.put((rank, w.numpy(), g.numpy(), m.conv3_1.conv1.weight.detach().cpu().numpy(), ts.epoch_stats(), rv_local, rv_synced))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph,dp_mode", [(False, 1), (True, 1), (True, 0)])
+@pytest.mark.parametrize("use_graph,dp_mode", [(False, 1), (True, 1), (True, 0), (True, "auto")])
 def test_two_rank_data_parallel_step(use_graph, dp_mode, synth):
     import nunet_amd
     ctx = mp.get_context("spawn")
@@ -94,10 +102,14 @@ def test_two_rank_data_parallel_step(use_graph, dp_mode, synth):
     expect = w0 - 1e-2 * (gsum / 2 + 1e-4 * w0)
     assert np.abs(res[0][0] - expect).max() <= 2e-2 * 1e-2 * np.abs(gsum).max() + 1e-7
     assert np.isfinite(res[0][3][0]) and abs(res[0][3][0] - res[1][3][0]) < 0.5
+    # BN buffer policy: local statistics differ between the replicas, after sync_bn_buffers() both hold rank 0's
+    assert not np.array_equal(res[0][4], res[1][4])
+    assert np.array_equal(res[0][5], res[0][4]) and np.array_equal(res[1][5], res[0][4])
 
 
 def _bucket0_worker(port, q):
-    os.environ.update(NUNET_DP_MODE="2", NUNET_FORCE_DP="1", RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(NUNET_DP_MODE="2", NUNET_FORCE_DP="1", NUNET_DEBUG_SPIN_US="2000", RANK="0", WORLD_SIZE="1",
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     import nunet_amd
     from nunet_amd import _lib as L
@@ -115,28 +127,30 @@ def _bucket0_worker(port, q):
         batches.append((torch.from_numpy(img).cuda(), torch.from_numpy(msk).cuda()))
     ts.capture(*batches[0])
     b0, _ = ts._buckets
-    side, early = torch.cuda.Stream(), torch.cuda.Stream()
-    snap, snap_early = torch.empty_like(b0), torch.empty_like(b0)   # allocated up front: a device malloc would synchronise
-    ok_wait, stale_without = [], []
+    side = torch.cuda.Stream()
+    snap = torch.empty_like(b0)                           # allocated up front: a device malloc would synchronise
+    ok_wait, lead_ms = [], []
     for x, t in batches[1:]:
         ts.x.copy_(x); ts.t.copy_(t)
+        b0.zero_()                                         # stale on purpose: only this pass can make the snapshot right
         torch.cuda.synchronize()
+        e_snap, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ts.g_fb.replay()                                   # forward + loss + whole backward, one graph, still running
-        with torch.cuda.stream(early):
-            snap_early.copy_(b0, non_blocking=True)        # no wait: sees the scratch before this pass has filled it
+        e_end.record()                                     # end of the pass (caller's stream)
         L.check(L.lib().nunet_plan_bucket0_wait(ts.pl.handle, side.cuda_stream), "bucket0_wait")
         with torch.cuda.stream(side):
             snap.copy_(b0, non_blocking=True)              # ordered after "bucket 0 complete" only
+            e_snap.record()
         torch.cuda.synchronize()
         ok_wait.append(bool(torch.equal(snap, b0)) and float(b0.abs().sum()) > 0)
-        stale_without.append(not torch.equal(snap_early, b0))
+        lead_ms.append(e_snap.elapsed_time(e_end))         # > 0: the snapshot was complete before the pass ended
         ts.g_opt.replay()
     # and the full step in this layout still trains
     for x, t in batches:
         ts.step(x, t)
     torch.cuda.synchronize()
     loss, iou = ts.epoch_stats()
-    q.put((ok_wait, stale_without, loss))
+    q.put((ok_wait, lead_ms, loss))
     dist.destroy_process_group()
 
 
@@ -158,8 +172,66 @@ def test_bucket0_event_orders_the_exchange_inside_the_graph():
                 break
     p.join(60)
     assert res is not None and p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
-    ok_wait, stale_without, loss = res
+    ok_wait, lead_ms, loss = res
     assert all(ok_wait), ok_wait
-    # (stale_without is informational: on this runtime a copy enqueued on a fresh stream right after hipGraphLaunch shares
-    #  a hardware queue with nodes of the graph and runs behind them, so the unordered snapshot is not reliably stale)
+    # control: phase 2 is headed by a 2 ms spin kernel (NUNET_DEBUG_SPIN_US), so a stream that is released by the
+    # bucket-0 event - and not by the end of the graph - finishes its copy of the 27 MB bucket at least 1 ms before the
+    # pass ends. (A copy that merely queued behind the whole graph would give a negative lead.)
+    print("bucket-0 lead over the end of the pass (ms):", lead_ms)
+    assert min(lead_ms) > 1.0, lead_ms
     assert np.isfinite(loss)
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("NUNET_DP_MODE", None)                 # auto: layouts 1 and 2 are timed, the faster is kept
+    import torch.distributed as dist
+    import nunet_amd
+    from nunet_amd.trainer import TrainStep
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    synth = nunet_amd.synth
+    torch.manual_seed(100 + rank)                          # ranks initialise differently: the TrainStep broadcasts rank 0's state
+    m = nunet_amd.archs.NestedUNet(1, 3, False, dtype="bf16").cuda().train()
+    ts = TrainStep(m, (16, 3, 96, 96), lr=1e-2)
+    assert ts.world == world and ts.dp
+    img, msk = synth.synth_batch(16, 96, 96, 3, 1, seed=700 + rank)
+    x, t = torch.from_numpy(img).cuda(), torch.from_numpy(msk).cuda()
+    ts.capture(x, t)
+    for _ in range(3):
+        ts.step(x, t)
+    torch.cuda.synchronize()
+    loss, _ = ts.epoch_stats()
+    w = m.conv3_1.conv1.weight.detach().float().cpu().numpy()
+    q.put((rank, w, loss, ts.dp_mode, ts.dp_choice))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL cannot put two ranks on one device")
+def test_rccl_two_gpus_replicas_stay_identical():
+    """The real exchange: two ranks on two GPUs over RCCL, step layout chosen by measurement (NUNET_DP_MODE auto).
+    Replicas that were initialised differently are identical after construction and stay identical through training."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    res = {}
+    for _ in range(150):
+        try:
+            r = q.get(timeout=2)
+            res[r[0]] = r[1:]
+            if len(res) == 2:
+                break
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    for p in procs:
+        p.join(60)
+    assert len(res) == 2 and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.isfinite(res[0][1]) and np.isfinite(res[1][1])
+    assert res[0][2] == res[1][2] and res[0][2] in (1, 2)          # the same measured layout on both ranks
+    print("layout chosen:", res[0][2], "ms (layout 1, layout 2):", res[0][3])

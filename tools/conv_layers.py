@@ -1,0 +1,95 @@
+"""Per-layer conv3x3 timings on the NestedUNet 96x96 bs16 shapes: forward conv1 (plain, two sources), conv2 (BatchNorm
+input transform), dgrad2 (BN-backward input transform + fused reduce epilogue), dgrad1 (BN-backward input transform,
+split destination). Each case is captured into a hipGraph of R launches and replayed: us per launch incl. the ~3 us
+same-stream node gap the real step also pays.   NUNET_CONV_SMALL=1 python tools/conv_layers.py"""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import nunet_amd
+from nunet_amd import _lib as L
+dt = L.BF16
+N = int(os.environ.get("NB", "16")); HW = int(os.environ.get("HW", "96")); R = 20
+NBF = [32, 64, 128, 256, 512]
+bf = torch.bfloat16
+keep = []
+
+def t(*shape, scale=1.0):
+    x = (torch.randn(*shape, device="cuda") * scale).to(bf); keep.append(x); return x
+
+def f32(n, fill=None):
+    x = torch.randn(n, device="cuda") if fill is None else torch.full((n,), fill, device="cuda"); keep.append(x); return x
+
+def time_graph(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(R): fn()
+    torch.cuda.synchronize()
+    for _ in range(3): g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000.0 / (10 * R)
+
+def conv(H, c0, c1, cout, lt=0, bnr=False, d1=0, ws=None):
+    d = L.ConvDesc()
+    d.dtype = dt; d.N = N; d.H = H; d.W = H
+    s0 = t(N, H, H, c0); d.src0 = L.ptr(s0).value; d.C0 = c0; d.P0 = c0
+    if c1:
+        s1 = t(N, H, H, c1); d.src1 = L.ptr(s1).value; d.C1 = c1; d.P1 = c1
+    w = t(9 * cout * (c0 + c1), scale=0.05); d.wpack = L.ptr(w).value
+    y = t(N, H, H, cout - d1); d.dst0 = L.ptr(y).value; d.D0 = cout - d1; d.Q0 = cout - d1
+    if d1:
+        y1 = t(N, H, H, d1); d.dst1 = L.ptr(y1).value; d.D1 = d1; d.Q1 = d1
+    if ws is not None:
+        d.splitk_ws = L.ptr(ws).value; d.splitk_ws_floats = ws.numel()
+    if lt == 0 or lt == 1:
+        st = L.fx_zeros(cout, "cuda"); keep.append(st); d.stats = L.ptr(st).value
+    if lt:
+        cin = c0
+        g, b = f32(cin, 1.0), f32(cin, 0.0)
+        d.in_tf = lt; d.tf_gamma = L.ptr(g).value; d.tf_beta = L.ptr(b).value
+        fx = L.fx_zeros(cin, "cuda"); keep.append(fx); d.tf_fx = L.ptr(fx).value
+        mi = f32(2 * cin, 1.0); d.tf_mean_invstd = L.ptr(mi).value
+        store = t(N, H, H, cin); d.tf_store = L.ptr(store).value; d.tf_ps = cin
+        d.tf_eps = 1e-5; d.tf_momentum = 0.1
+        if lt == 1:
+            d.tf_training = 1
+            # plausible sums: mean 0, E[x^2] = 1
+            v = torch.zeros(2 * cin, dtype=torch.float64); v[cin:] = N * H * H
+            fx2 = L.fx_encode(v, cin, "cuda"); keep.append(fx2); d.tf_fx = L.ptr(fx2).value
+        else:
+            yy = t(N, H, H, cin); d.tf_y = L.ptr(yy).value; d.tf_py = cin
+    if bnr:
+        y1 = t(N, H, H, cout); d.bn_y = L.ptr(y1).value; d.bn_py = cout
+        mi2 = f32(2 * cout, 1.0); d.bn_mean_invstd = L.ptr(mi2).value
+        g2, b2 = f32(cout, 1.0), f32(cout, 0.0); d.bn_gamma = L.ptr(g2).value; d.bn_beta = L.ptr(b2).value
+        sm = L.fx_zeros(cout, "cuda"); keep.append(sm); d.bn_sums = L.ptr(sm).value
+    keep.append(d)
+    return time_graph(lambda: L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream())))
+
+print("%-8s %10s %10s %10s %10s   (us per launch, bf16 N=%d %dx%d)" % ("block", "conv1", "conv2", "dgrad2", "dgrad1", N, HW, HW))
+tot = [0.0] * 4
+for i in range(5):
+    H = HW >> i; f = NBF[i]
+    ws = torch.zeros(8 * N * H * H * (5 * f), device="cuda") if i >= 3 else None
+    for j in range(5 - i):
+        if j == 0:
+            c0, c1 = (32 if i == 0 else NBF[i - 1]), 0
+        else:
+            c0, c1 = j * f, NBF[i + 1]
+        a = conv(H, c0, c1, f, ws=ws)
+        b = conv(H, f, 0, f, lt=1, ws=ws)
+        c = conv(H, f, 0, f, lt=2, bnr=True, ws=ws)
+        if i == 0 and j == 0:
+            dd = 0.0
+        else:
+            dd = conv(H, f, 0, c0 + c1, lt=2, d1=c1, ws=ws)
+        print("B%d%d      %10.1f %10.1f %10.1f %10.1f" % (i, j, a, b, c, dd))
+        for k, v in enumerate((a, b, c, dd)): tot[k] += v
+print("sum      %10.1f %10.1f %10.1f %10.1f   total %.1f" % (*tot, sum(tot)))

@@ -7,6 +7,14 @@ Same artefacts as the reference: models/<name>/config.yml (trains.py:206-207),
 models/<name>/log.csv with columns epoch, lr, loss, iou, val_loss, val_iou (:304-311,331-339),
 models/<name>/model.pth = state_dict at the best val IoU (:344-349), early stopping (:351-354).
 The `lr` column logs the scheduler's current lr (the reference logs the constant initial lr, :332).
+
+Data parallel (new capability; the reference is single-device, trains.py:223): launch one process per GPU,
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port 29500 \
+           train.py --gpus N [flags]
+--batch_size stays the PER-GPU batch (weak scaling: the global batch is N x batch_size, every replica normalises its
+BatchNorm over its own batch_size images like the single-GPU step), rank r consumes slice r of every global batch,
+gradients are averaged over RCCL, rank 0's BatchNorm buffers are broadcast before validation and rank 0 writes the
+artefacts.
 """
 import argparse
 import os
@@ -16,8 +24,10 @@ from collections import OrderedDict
 import torch
 import yaml
 
+import torch.distributed as dist
+
 import nunet_amd
-from nunet_amd import archs, losses
+from nunet_amd import archs, losses, parallel
 from nunet_amd.metrics import iou_counts, iou_from_counts
 from nunet_amd.trainer import TrainStep, cosine_lr
 from nunet_amd.utils import AverageMeter, str2bool
@@ -53,11 +63,17 @@ def parse_args():
     p.add_argument('--train_size', default=512, type=int)
     p.add_argument('--val_size', default=128, type=int)
     p.add_argument('--seed', default=41, type=int)
+    p.add_argument('--gpus', default=0, type=int, help='number of ranks this job was launched with (checked against WORLD_SIZE; 0: do not check)')
     return p.parse_args()
 
 
 def make_split(n, h, w, cin, ncls, seed):
-    img, msk = nunet_amd.synth.synth_batch(n, h, w, cin, ncls, seed=seed)
+    """Seeded synthetic split. One class, three channels: the learnable blob set (images rendered from the masks,
+    the set behind tests/golden/train_log_blobs.npz); other shapes: independent noise images and blob masks."""
+    if cin == 3 and ncls == 1:
+        img, msk = nunet_amd.synth.synth_blob_pairs(n, h, w, seed=seed)
+    else:
+        img, msk = nunet_amd.synth.synth_batch(n, h, w, cin, ncls, seed=seed)
     return torch.from_numpy(img), torch.from_numpy(msk)
 
 
@@ -84,15 +100,21 @@ def validate(config, data, model, criterion):
 
 def main():
     config = vars(parse_args())
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    rank, world = parallel.init_from_env('nccl')
+    if config['gpus'] and config['gpus'] != world:
+        raise SystemExit('--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d' % (config['gpus'], world, config['gpus']))
     if config['name'] is None:
         config['name'] = '%s_%s_%s' % (config['dataset'], config['arch'], 'wDS' if config['deep_supervision'] else 'woDS')
-    os.makedirs('models/%s' % config['name'], exist_ok=True)
-    print('-' * 20)
-    for k, v in config.items():
-        print('%s: %s' % (k, v))
-    print('-' * 20)
-    with open('models/%s/config.yml' % config['name'], 'w') as f:
-        yaml.dump(config, f)
+    if rank == 0:
+        os.makedirs('models/%s' % config['name'], exist_ok=True)
+        print('-' * 20)
+        for k, v in config.items():
+            print('%s: %s' % (k, v))
+        print('-' * 20)
+        with open('models/%s/config.yml' % config['name'], 'w') as f:
+            yaml.dump(config, f)
 
     criterion = losses.__dict__[config['loss']]().cuda()
     torch.manual_seed(config['seed'])
@@ -103,9 +125,11 @@ def main():
     # the synthetic splits live in HBM (a few MB); batches are gathered on the device
     train = tuple(v.cuda() for v in make_split(config['train_size'], h, w, config['input_channels'], config['num_classes'], 1000))
     val = tuple(v.cuda() for v in make_split(config['val_size'], h, w, config['input_channels'], config['num_classes'], 2000))
-    steps = config['train_size'] // bs          # drop_last=True (trains.py:296)
+    steps = config['train_size'] // (bs * world)          # drop_last=True (trains.py:296); global batch = world x bs
 
     fused = config['optimizer'] == 'SGD' and config['loss'] == 'BCEDiceLoss'   # TrainStep fuses BCEDice; other losses go through autograd
+    if world > 1 and not fused:
+        raise SystemExit('data parallel runs the fused step: --optimizer SGD --loss BCEDiceLoss')
     if fused:
         model.train()
         ts = TrainStep(model, (bs, config['input_channels'], h, w), lr=config['lr'], momentum=config['momentum'],
@@ -132,9 +156,15 @@ def main():
             ts.set_lr(lr)
             ts.reset_meters()
             for k in range(steps):
-                idx = perm[k * bs:(k + 1) * bs]
+                lo = (k * world + rank) * bs                             # slice `rank` of global batch k
+                idx = perm[lo:lo + bs]
                 ts.step(train[0][idx], train[1][idx])
             tl, ti = ts.epoch_stats()
+            if world > 1:                                                # epoch means over all ranks' (equal-sized) batches
+                m = torch.tensor([tl, ti], dtype=torch.float64, device='cuda')
+                dist.all_reduce(m)
+                tl, ti = (m / world).tolist()
+                ts.sync_bn_buffers()                                     # rank 0's running statistics are the model's
         else:
             for gpar in optimizer.param_groups:
                 gpar['lr'] = lr
@@ -156,25 +186,31 @@ def main():
                 mi.update(iou_from_counts(iou_counts(last.detach().contiguous(), tb)), bs)
             tl, ti = ml.avg, mi.avg
         torch.cuda.synchronize()
-        ips = steps * bs / (time.perf_counter() - t0)
-        val_log = validate(config, val, model, criterion)
-        print('Epoch [%d/%d] loss %.4f - iou %.4f - val_loss %.4f - val_iou %.4f - %.0f img/s'
-              % (epoch, config['epochs'], tl, ti, val_log['loss'], val_log['iou'], ips))
-        for k, v in zip(log, (epoch, lr, tl, ti, val_log['loss'], val_log['iou'], ips)):
-            log[k].append(v)
-        with open('models/%s/log.csv' % config['name'], 'w') as f:
-            f.write(','.join(log.keys()) + '\n')
-            for r in range(len(log['epoch'])):
-                f.write(','.join(str(log[k][r]) for k in log) + '\n')
+        ips = steps * bs * world / (time.perf_counter() - t0)
+        val_log = validate(config, val, model, criterion)                # every rank: identical replicas, identical numbers
         trigger += 1
-        if val_log['iou'] > best_iou:
-            torch.save(model.state_dict(), 'models/%s/model.pth' % config['name'])
+        improved = val_log['iou'] > best_iou
+        if rank == 0:
+            print('Epoch [%d/%d] loss %.4f - iou %.4f - val_loss %.4f - val_iou %.4f - %.0f img/s'
+                  % (epoch, config['epochs'], tl, ti, val_log['loss'], val_log['iou'], ips))
+            for k, v in zip(log, (epoch, lr, tl, ti, val_log['loss'], val_log['iou'], ips)):
+                log[k].append(v)
+            with open('models/%s/log.csv' % config['name'], 'w') as f:
+                f.write(','.join(log.keys()) + '\n')
+                for r in range(len(log['epoch'])):
+                    f.write(','.join(str(log[k][r]) for k in log) + '\n')
+            if improved:
+                torch.save(model.state_dict(), 'models/%s/model.pth' % config['name'])
+                print("=> saved best model")
+        if improved:
             best_iou = val_log['iou']
-            print("=> saved best model")
             trigger = 0
         if 0 <= config['early_stopping'] <= trigger:
-            print("=> early stopping")
+            if rank == 0:
+                print("=> early stopping")
             break
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
