@@ -45,14 +45,14 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, 16) = the GPU box's CPU share")
     return ap.parse_args()
 
 
 def cpu_baseline(args, budget_s):
-    """Reference CPU path: the oracle restatement (stock torch fp32 on the host cores),
-    same workload, bounded sample."""
+    """Reference CPU path: the oracle restatement (stock torch fp32 on the host cores), bounded samples of
+    (a) the workload of this line (same batch / size) and (b) BASELINE.json configs[0] (batch 8, 96x96)."""
     import numpy as np
     from oracle import nunet_oracle as O
     import nunet_amd
@@ -60,22 +60,47 @@ def cpu_baseline(args, budget_s):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = args.cpu_threads or min(cores, 16)
     torch.set_num_threads(cores)
-    st = synth.closed_form_state(args.num_classes, 3, args.deep_supervision, True)
-    net = O.OracleNet(st, args.num_classes, 3, args.deep_supervision)
-    opt = O.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
-    img, msk = synth.synth_batch(args.batch, args.size, args.size, 3, args.num_classes, seed=1234)
-    x, t = torch.from_numpy(img), torch.from_numpy(msk)
-    O.train_step(net, opt, x, t)                       # warm-up (allocator, oneDNN primitives)
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while time.perf_counter() < t_end and len(times) < 20:
-        t0 = time.perf_counter()
-        O.train_step(net, opt, x, t)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": args.batch / med, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d steps of bs=%d %dx%d fp32 train step (oracle/nunet_oracle.py, torch CPU), median %.0f ms/step"
-                      % (len(times), args.batch, args.size, args.size, med * 1e3)}
+
+    def sample(batch, size, budget):
+        st = synth.closed_form_state(args.num_classes, 3, args.deep_supervision, True)
+        net = O.OracleNet(st, args.num_classes, 3, args.deep_supervision)
+        opt = O.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+        img, msk = synth.synth_batch(batch, size, size, 3, args.num_classes, seed=1234)
+        x, t = torch.from_numpy(img), torch.from_numpy(msk)
+        O.train_step(net, opt, x, t)                       # warm-up (allocator, oneDNN primitives)
+        times = []
+        t_end = time.perf_counter() + budget
+        while time.perf_counter() < t_end and len(times) < 20:
+            t0 = time.perf_counter()
+            O.train_step(net, opt, x, t)
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        return batch / med, "%d steps of bs=%d %dx%d fp32 train step (oracle/nunet_oracle.py, torch CPU), median %.0f ms/step" % (
+            len(times), batch, size, size, med * 1e3)
+
+    v, smp = sample(args.batch, args.size, budget_s * 0.6)
+    out = {"value": v, "unit": "images/sec", "cores": cores, "kind": "port", "sample": smp}
+    if not (args.batch == 8 and args.size == 96):
+        v8, smp8 = sample(8, 96, budget_s * 0.4)
+        out["configs0_bs8_96"] = {"value": v8, "unit": "images/sec", "sample": smp8}
+    return out
+
+
+def _sha16(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+KERNEL_SOURCES = ["conv3x3.hip", "elementwise.hip", "plan.hip", "common.h"]
+
+
+def kernel_source_hash():
+    """Identity of the kernels a committed PMC file was collected on (profiles/*_pmc_traffic.json carries it)."""
+    d = os.path.join(ROOT, "pytorch_nested-unet_amd", "csrc")
+    return _sha16([os.path.join(d, f) for f in KERNEL_SOURCES])
 
 
 def main():
@@ -137,9 +162,9 @@ def main():
 
     roofline = None
     if not args.no_roofline and rank == 0 and world == 1:     # single-process leg: no collectives inside
-        # live per-kernel timing: the same step, eager, hipEvents around every launch on its launch
-        # stream; single-lane issue for this pass so that kernels are timed alone (the timed region
-        # above runs the lanes concurrently)
+        # Live per-kernel timing of the same step: eager, single-lane issue (kernels alone on the device), every launch
+        # through hipExtLaunchKernelGGL with a start/stop event pair = the dispatch's own begin/end timestamps (the
+        # figures rocprofv3 --kernel-trace reports; profiles/r02_summary.md holds that trace of the same command).
         L.check(L.lib().nunet_plan_set_multistream(ts.pl.handle, 0), "set_multistream")
         for _ in range(2):
             ts._fwd_bwd(); ts._opt()
@@ -157,6 +182,7 @@ def main():
         avg_ms = top["ms"] / top["launches"]
         tflops = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
         gbs = top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9
+        # which roof bounds the dominant class: time at the MFMA peak vs time at the HBM peak of its ALGORITHMIC work
         mfma_bound = top["flops"] > 0 and (top["flops"] / (PEAK[args.dtype] * 1e12)) >= (top["bytes"] / (HBM_PEAK_GBS * 1e9))
         if mfma_bound:
             roofline = {"bound": "mfma", "achieved": tflops, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
@@ -164,26 +190,31 @@ def main():
         else:
             roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}
-        # HBM traffic of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction,
-        # MI355X_MICROARCH.md "HBM"): bytes per launch, averaged over its launches in a step
+        roofline["achieved_tflops"] = tflops
+        roofline["achieved_gbs"] = gbs
+        roofline["algorithmic_bytes_per_launch"] = top["bytes"] / top["launches"]
+        roofline["algorithmic_flops_per_launch"] = top["flops"] / top["launches"]
+        # HBM traffic of that class from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+        # FETCH_SIZE x2 correction of MI355X_MICROARCH.md): attached only when the file was collected on THESE kernel
+        # sources and this workload; otherwise null (a stale figure is worse than none)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            pat = {"conv3x3_fwd_dgrad<BM128,BN64>": "void conv3x3_kernel<", "conv3x3_fwd_dgrad<BM256,BN32>": "Li4ELi1ELi2ELi1ELb0",
-                   "conv3x3_wgrad(Cout>=64)": "wgrad_pair_kernel", "conv3x3_wgrad(Cout=32)": "wgrad_pair_kernel"}.get(top["name"])
-            if pat and args.dtype == "bf16" and hw == 96 and n == 16:
-                for kname, rec in pmc.items():
-                    # (the BM128 class is the plain instantiation: template args ..., SK = false, BNR = false, ...)
-                    if pat in kname and "DF16b" in kname or (pat == "void conv3x3_kernel<" and kname.startswith(pat) and ", E, false, false," in kname):
-                        roofline["traffic"] = rec["hbm_bytes_per_launch_corrected"]
-                        roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-                        roofline["algorithmic_bytes_per_launch"] = top["bytes"] / top["launches"]
-                        break
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            same = pmc.get("kernel_source_sha16") == kernel_source_hash() and pmc.get("workload") == [args.dtype, n, hw]
+            rec = pmc.get("classes", {}).get(top["name"])
+            if same and rec:
+                roofline["traffic"] = rec["hbm_bytes_per_launch_corrected"]
+                roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            else:
+                roofline["traffic_note"] = "profiles/r02_pmc_traffic.json was collected on different kernel sources / workload: not attached"
         except Exception:
             pass
         roofline["kernel"] = top["name"]
         roofline["avg_launch_us"] = avg_ms * 1e3
         roofline["launches_per_step"] = top["launches"] / reps
         roofline["share_of_kernel_time"] = top["ms"] / tot
+        roofline["timing"] = "per-dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events), single lane, eager"
+        roofline["sum_kernel_us_per_step"] = tot * 1e3 / reps
+        roofline["overlap_factor"] = (tot / reps) / ms_per_step     # summed kernel time / wall time of the multi-lane graph step
         roofline["classes"] = [{"name": e["name"], "launches_per_step": e["launches"] / reps,
                                 "us_per_step": e["ms"] * 1e3 / reps,
                                 "tflops": (e["flops"] / (e["ms"] * 1e-3) / 1e12) if e["ms"] > 0 else 0.0,

@@ -40,7 +40,7 @@ int nunet_check_launch(const char* what);
 // stream around every kernel, aggregated per kernel class. Off by default.
 // ---------------------------------------------------------------------------
 enum {
-  PC_CONV_M256N32 = 0, PC_CONV_M128N64, PC_WGRAD_1x4, PC_WGRAD_2x2, PC_BN_FWD, PC_BN_BWD_REDUCE,
+  PC_CONV_M256N32 = 0, PC_CONV_M128N64, PC_CONV_M128N32, PC_WGRAD_1x4, PC_WGRAD_2x2, PC_BN_FWD, PC_BN_BWD_REDUCE,
   PC_BN_BWD_APPLY, PC_UP_FWD, PC_UP_BWD, PC_POOL, PC_HEAD, PC_PACK, PC_UNPACK, PC_LOSS, PC_SGD,
   PC_LAYOUT, PC_COUNT
 };

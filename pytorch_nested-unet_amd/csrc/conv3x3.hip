@@ -779,9 +779,8 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.S = 1; p.slabs = nullptr; p.slab_stride = 0;
   p.nch0 = p.C0 / C::KC;
   p.nch = p.nch0 + p.C1 / C::KC;
-  static int sk_max_items = -1;
-  if (sk_max_items < 0) { const char* e = getenv("NUNET_SK_MAXITEMS"); sk_max_items = e ? atoi(e) : 100; }
-  if (d->splitk_ws && items <= sk_max_items && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
+  // (measured on the 96x96 workload, tools/conv_layers.py: below ~60 items a split pays for its finalize launch, above it does not)
+  if (d->splitk_ws && items <= 60 && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
     int S = (int)((320 + items - 1) / items);
     if (S > p.nch / 2) S = p.nch / 2;
     const long long need = (long long)S * d->N * d->H * d->W * p.Cout;
@@ -803,7 +802,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   const long grid = (items + rounds - 1) / rounds;
   const double px = (double)d->N * d->H * d->W;
   const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
-  ProfScope ps(C::BN == 32 ? PC_CONV_M256N32 : PC_CONV_M128N64,  /* BN 64 configs share a class */ 2.0 * 9 * acin * p.Cout * px,
+  ProfScope ps(C::BN == 64 ? PC_CONV_M128N64 : C::BM == 256 ? PC_CONV_M256N32 : PC_CONV_M128N32, 2.0 * 9 * acin * p.Cout * px,
                (px * (acin * (lt == 2 ? 2 : 1) + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
   if (p.S > 1) {
     launch_conv_lt<T, WM, WN, SM, SN, true, false>(lt, (unsigned)grid, dyn, st, p);

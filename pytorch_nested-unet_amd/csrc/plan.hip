@@ -594,7 +594,9 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
       // K-split of the weight gradient: the two problems of a block share one launch, the one with fewer input
       // channels takes half the workgroups (fewer, fatter slices: less slab traffic)
       const ConvL& o = cv ? n.c1 : n.c2;
-      c.wg_target = c.cinpad < o.cinpad ? 128 : 256;
+      static int wt_small = 0, wt_big = 0;
+      if (!wt_small) { const char* e = getenv("NUNET_WG_TARGETS"); if (!e || sscanf(e, "%d,%d", &wt_small, &wt_big) != 2) { wt_small = 128; wt_big = 256; } }
+      c.wg_target = c.cinpad < o.cinpad ? wt_small : wt_big;
       nunet_wgrad_desc wd; memset(&wd, 0, sizeof(wd));
       wd.N = cfg->N; wd.H = P->hl[n.i]; wd.W = P->wl[n.i]; wd.C0 = c.cinpad; wd.Cout = c.cout; wd.target_wgs = c.wg_target; wd.max_slabs = ks_max;
       c.ks = nunet_conv3x3_wgrad_slabs(&wd);
@@ -1470,7 +1472,15 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       int rx[4] = {-1, -1, -1, -1}, r_in = -1, r_up = -1;
       if (n.in_prefix == 0) r_in = (i == 0 ? R_IMG : rb + B_PIN);
       else { for (int q = 0; q < n.in_prefix && q < 4; ++q) rx[q] = R_X + i * 5 + q; r_up = rb + B_UP; }
-      S.add(wlane, 1, 0.f, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
+      static int abl = -1; if (abl < 0) { const char* e = getenv("NUNET_ABLATE"); abl = e ? atoi(e) : 0; }   /* ABLATE-DIAG */
+      // The weight gradients of the shallow blocks of the critical chain (B04, B13, B22: full-chip launches) are held
+      // back until the chain reaches the deep levels (B31 ..., grid-starved kernels that leave most CUs idle): they run
+      // on lane 4 behind a dependency on the gradient that B22's upsample-backward hands to B31
+      static int defer = -1; if (defer < 0) { const char* e = getenv("NUNET_WG_DEFER"); defer = e ? atoi(e) : 0; }
+      int wl = wlane, r_gate = -1;
+      if (defer && !P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
+      if (!(abl & 1))   /* ABLATE-DIAG */
+      S.add(wl, 1, 0.f, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up, r_gate}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
             [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w1, &w2, ls); g_prof_alg_cin = 0; return r; });
     }
     // "bucket 0 complete" (data-parallel exchange beside the rest of the backward pass, nunet_plan_bucket0_*): on the otherwise
@@ -1505,6 +1515,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   // slab sums of the nodes this call covered (phase-1 nodes were already reduced inside the pass when bucket 0 is signalled there)
   if (phases & 3) {
     const int lo = k_lo, hi = (b0_inside && S.multi) ? k_split - 1 : k_hi;
+    { const char* e = getenv("NUNET_ABLATE"); if (e && (atoi(e) & 2)) return NUNET_OK; }   /* ABLATE-DIAG */
     if (hi >= lo) CK(launch_reduce(P, arena, lo, hi, st));
   }
   if (!(phases & 4)) return NUNET_OK;

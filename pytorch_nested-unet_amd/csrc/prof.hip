@@ -37,9 +37,9 @@ void nunet_prof_kernel_events(hipEvent_t* e0, hipEvent_t* e1) {
 }
 
 static const char* kNames[PC_COUNT] = {
-    "conv3x3_fwd_dgrad<BM256,BN32>", "conv3x3_fwd_dgrad<BM128,BN64>", "conv3x3_wgrad(Cout=32)", "conv3x3_wgrad(Cout>=64)",
+    "conv3x3_fwd_dgrad<BM256,BN32>", "conv3x3_fwd_dgrad<BM128,BN64>", "conv3x3_fwd_dgrad<BM128,BN32>", "conv3x3_wgrad(Cout=32)", "conv3x3_wgrad(Cout>=64)",
     "bn_relu_fwd(+pool)", "bn_relu_bwd_reduce", "bn_relu_bwd_apply", "upsample2x_fwd", "upsample2x_bwd",
-    "maxpool2x2", "head_1x1", "pack_weights", "unpack_grads", "bce_dice+iou", "sgd_step", "layout"};
+    "maxpool2x2", "head_1x1", "pack_weights", "wgrad_slab_reduce/unpack", "bce_dice+iou", "sgd_step", "layout"};
 
 extern "C" int nunet_profile_begin(void) {
   g_recs.clear(); g_open.clear();
