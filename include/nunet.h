@@ -182,6 +182,19 @@ typedef struct {
 int nunet_bn_relu_bwd_reduce(const nunet_bn_bwd_desc* d, nunet_stream_t s);
 int nunet_bn_relu_bwd_apply(const nunet_bn_bwd_desc* d, nunet_stream_t s);
 
+/* BatchNorm+ReLU backward REDUCE fused into the kernel that COMPLETES a gradient tensor. The gradient of a block output
+ * x_{i,j} is accumulated in its level-buffer slot by several kernels (dgrads of later blocks of the level, an
+ * upsample-backward, a pool-backward, a head-backward); the LAST of them can take the reduce pass of that block's
+ * second BatchNorm (sum dz, sum dz * xhat, as nunet_bn_relu_bwd_reduce) on the values it has just stored, which saves a
+ * launch and a second read of the gradient. `*_bnr` entry points take this descriptor (NULL: plain kernel); C = the
+ * channel count of the call. */
+typedef struct {
+  const void* y; int32_t PY;        /* raw conv output the BatchNorm normalised, [pixels][PY] */
+  const float* mean_invstd;         /* [2][C] saved by the BatchNorm forward */
+  const float* gamma; const float* beta;
+  int64_t* sums;                    /* fixed-point sums [rep][2][C], pre-zeroed */
+} nunet_bnr_desc;
+
 /* ------------------------------------------------------------------------ */
 /* MaxPool2d(2,2) (archs1.py:82) and Upsample(x2, bilinear, align_corners)   */
 /* (archs1.py:83)                                                            */
@@ -192,12 +205,18 @@ int nunet_maxpool2x2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t
 int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
                          const void* x, int32_t PX, const void* dy, int32_t PDY,
                          void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s);
+int nunet_maxpool2x2_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                             const void* x, int32_t PX, const void* dy, int32_t PDY,
+                             void* dx, int32_t PDX, int32_t accumulate, const nunet_bnr_desc* bnr, nunet_stream_t s);
 /* H, W are the INPUT (low-res) extents; output is 2H x 2W */
 int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
                          const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s);
 int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
                          const void* dy, int32_t PDY, void* dx, int32_t PDX,
                          int32_t accumulate, nunet_stream_t s);
+int nunet_upsample2x_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                             const void* dy, int32_t PDY, void* dx, int32_t PDX,
+                             int32_t accumulate, const nunet_bnr_desc* bnr, nunet_stream_t s);
 
 /* ------------------------------------------------------------------------ */
 /* 1x1 heads: nn.Conv2d(32, num_classes, 1) at archs1.py:105-111,133-143     */
@@ -214,6 +233,10 @@ int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, in
                    const void* x, int32_t PX, const float* w, const float* dlogits,
                    void* dx, int32_t PDX, int32_t accumulate,
                    float* dw_slabs, int32_t nslabs, nunet_stream_t s);
+int nunet_head_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K,
+                       const void* x, int32_t PX, const float* w, const float* dlogits,
+                       void* dx, int32_t PDX, int32_t accumulate,
+                       float* dw_slabs, int32_t nslabs, const nunet_bnr_desc* bnr, nunet_stream_t s);
 
 /* ------------------------------------------------------------------------ */
 /* BCEDiceLoss (losses.py:103-117), iou_score (metrics.py:6-18)              */

@@ -89,6 +89,10 @@ class BnBwdDesc(C.Structure):
                 ("dy", _vp), ("PDY", _i32)]
 
 
+class BnrDesc(C.Structure):
+    _fields_ = [("y", _vp), ("PY", _i32), ("mean_invstd", _vp), ("gamma", _vp), ("beta", _vp), ("sums", _vp)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", _i32), ("ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -116,10 +120,13 @@ _SIG = {
     "nunet_bn_relu_bwd_apply": (_i32, [C.POINTER(BnBwdDesc), _vp]),
     "nunet_maxpool2x2_fwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp]),
     "nunet_maxpool2x2_bwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "nunet_maxpool2x2_bwd_bnr": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(BnrDesc), _vp]),
     "nunet_upsample2x_fwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp]),
     "nunet_upsample2x_bwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _i32, _vp]),
+    "nunet_upsample2x_bwd_bnr": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _i32, C.POINTER(BnrDesc), _vp]),
     "nunet_head_fwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _vp]),
     "nunet_head_bwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "nunet_head_bwd_bnr": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, C.POINTER(BnrDesc), _vp]),
     "nunet_bce_dice_ws_bytes": (C.c_size_t, [_i32]),
     "nunet_bce_dice_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "nunet_bce_dice_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),

@@ -780,7 +780,9 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.nch0 = p.C0 / C::KC;
   p.nch = p.nch0 + p.C1 / C::KC;
   // (measured on the 96x96 workload, tools/conv_layers.py: below ~60 items a split pays for its finalize launch, above it does not)
-  if (d->splitk_ws && items <= 60 && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
+  static int sk_max_items = -1;
+  if (sk_max_items < 0) { const char* e = getenv("NUNET_SK_MAXITEMS"); sk_max_items = e ? atoi(e) : 60; }
+  if (d->splitk_ws && items <= sk_max_items && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
     int S = (int)((320 + items - 1) / items);
     if (S > p.nch / 2) S = p.nch / 2;
     const long long need = (long long)S * d->N * d->H * d->W * p.Cout;

@@ -5,6 +5,7 @@
 // Reference arithmetic: finished/archs1.py:17-21,82-83,105-111; losses.py:103-117;
 // metrics.py:6-18; trains.py:229-231.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -450,6 +451,58 @@ extern "C" int nunet_bn_relu_bwd_apply(const nunet_bn_bwd_desc* d, nunet_stream_
 }
 
 // ---------------------------------------------------------------------------
+// BatchNorm+ReLU backward REDUCE taken by the kernel that COMPLETES a gradient tensor (the last writer of a level-buffer
+// slot: an upsample-backward, a pool-backward or the head-backward), on the values it has just stored - instead of a
+// separate pass (nunet_bn_relu_bwd_reduce) that would read the gradient and the raw conv output again.
+// A thread's channel group is fixed (the launch geometry keeps grid stride % G == 0): coefficients and the two partial
+// sums of its EPV channels live in registers; the block reduces them in a fixed order, then one fixed-point add each.
+// ---------------------------------------------------------------------------
+struct BnrP { const void* y; int py; const float* mi; const float* gamma; const float* beta; long long* sums; int C; };
+template <typename T> struct BnrAcc {
+  static constexpr int EPV = Tr<T>::EPV;
+  float mean[EPV], istd[EPV], sc[EPV], sh[EPV], r1[EPV], r2[EPV];
+  __device__ __forceinline__ void init(const BnrP& b, int cg) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const int c = cg * EPV + e;
+      mean[e] = b.mi[c]; istd[e] = b.mi[b.C + c];
+      sc[e] = b.gamma[c] * istd[e]; sh[e] = __builtin_fmaf(-mean[e], sc[e], b.beta[c]);
+      r1[e] = 0.f; r2[e] = 0.f;
+    }
+  }
+  // `stored`: the gradient vector as written (rounded to T); pix: its pixel index in the BN's tensor
+  __device__ __forceinline__ void add(const BnrP& b, int cg, long long pix, const Vec16<T>& stored) {
+    const Vec16<T> yv = ld16((const T*)b.y + pix * b.py + cg * EPV);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float yy = yv.get(e);
+      const float dz = __builtin_fmaf(yy, sc[e], sh[e]) > 0.f ? stored.get(e) : 0.f;
+      r1[e] += dz; r2[e] += dz * ((yy - mean[e]) * istd[e]);
+    }
+  }
+  // s_part: 256 * 2 * EPV floats of LDS; G = channel groups; all 256 threads of the block call this
+  __device__ __forceinline__ void finish(const BnrP& b, float* s_part, int G) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s_part[(threadIdx.x * 2 + 0) * EPV + e] = r1[e]; s_part[(threadIdx.x * 2 + 1) * EPV + e] = r2[e]; }
+    __syncthreads();
+    const int ppb = blockDim.x / G;
+    for (int t = threadIdx.x; t < 2 * b.C; t += blockDim.x) {
+      const int v = t / b.C, c = t - v * b.C;
+      const int g = c / EPV, e = c - g * EPV;
+      float sum = 0.f;
+      for (int q = 0; q < ppb; ++q) sum += s_part[((q * G + g) * 2 + v) * EPV + e];
+      fx_add(b.sums + ((size_t)((blockIdx.x & (bn_sum_replicas(b.C) - 1)) * 2 + v) * b.C + c) * NUNET_FX_WORDS, sum);
+    }
+  }
+};
+static int bnr_fill(BnrP& b, const nunet_bnr_desc* d, int C, int dtype) {
+  b.y = d->y; b.py = d->PY; b.mi = d->mean_invstd; b.gamma = d->gamma; b.beta = d->beta; b.sums = (long long*)d->sums; b.C = C;
+  NUNET_REQUIRE(d->y && d->mean_invstd && d->gamma && d->beta && d->sums && d->PY % (16 / dtype_size(dtype)) == 0 && d->PY >= C,
+                "fused BN-backward reduce: y, mean/invstd, gamma, beta, sums and an aligned pitch are required");
+  return NUNET_OK;
+}
+
+// ---------------------------------------------------------------------------
 // MaxPool2d(2,2)
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -474,11 +527,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     st16(y + q * PY + cg * EPV, o);
   }
 }
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int PX, const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc) {
+template <typename T, bool BNR>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int PX, const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc, BnrP bn) {
   constexpr int EPV = Tr<T>::EPV;
   const int G = C / EPV, H2 = H / 2, W2 = W / 2;
   const int64_t total = (int64_t)N * H2 * W2 * G;
+  __shared__ float s_part[BNR ? 256 * 2 * EPV : 1];
+  BnrAcc<T> ba;
+  if constexpr (BNR) ba.init(bn, threadIdx.x % G);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int cg, qx, qy, n; long long q;
     dec4(dc, i, cg, q, qx, qy, n);
@@ -509,8 +565,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         o.set(e, am[e] == k ? base + g.get(e) : base);
       }
       st16(q4, o);
+      if constexpr (BNR) ba.add(bn, cg, p00 + (k >> 1) * W + (k & 1), o);
     }
   }
+  if constexpr (BNR) ba.finish(bn, s_part, G);
 }
 template <typename T> static int launch_maxpool_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
@@ -518,10 +576,22 @@ template <typename T> static int launch_maxpool_fwd(int N, int H, int W, int C, 
   NUNET_LAUNCH((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
   return nunet_check_launch("maxpool_fwd");
 }
-template <typename T> static int launch_maxpool_bwd(int N, int H, int W, int C, const void* x, int PX, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
+// (block size 256 and a grid stride that is a multiple of the channel groups keep a thread's channel group fixed)
+static int bnr_grid(int64_t total, int per_block, int G, int cap) {
+  int g = grid_for(total, per_block, cap);
+  (void)G;            // 256 % G == 0 is checked by the callers, so any grid keeps (grid * 256) % G == 0
+  return g;
+}
+template <typename T> static int launch_maxpool_bwd(int N, int H, int W, int C, const void* x, int PX, const void* dy, int PDY, void* dx, int PDX, int acc, const nunet_bnr_desc* bnr, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
-  ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * (acc ? 3.25 : 2.25), st);
-  NUNET_LAUNCH((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
+  ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * ((acc ? 3.25 : 2.25) + (bnr ? 1.0 : 0.0)), st);
+  BnrP b; memset(&b, 0, sizeof(b));
+  if (bnr) {
+    NUNET_REQUIRE(256 % (C / Tr<T>::EPV) == 0, "maxpool_bwd: fused BN reduce needs C / %d to divide 256", Tr<T>::EPV);
+    int rc = bnr_fill(b, bnr, C, Tr<T>::DT); if (rc) return rc;
+    NUNET_LAUNCH((maxpool_bwd_kernel<T, true>), dim3(grid_for(total, 256 * 2, 1024)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2), b);
+  } else
+    NUNET_LAUNCH((maxpool_bwd_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2), b);
   return nunet_check_launch("maxpool_bwd");
 }
 static int ew_check(const char* what, int dtype, int N, int H, int W, int C, int p0, int p1) {
@@ -536,11 +606,14 @@ extern "C" int nunet_maxpool2x2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t
   NUNET_REQUIRE(x && y && H % 2 == 0 && W % 2 == 0, "maxpool_fwd: needs even H, W");
   return NUNET_DISPATCH(dtype, launch_maxpool_fwd, N, H, W, C, x, PX, y, PY, (hipStream_t)s);
 }
-extern "C" int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
+extern "C" int nunet_maxpool2x2_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, const nunet_bnr_desc* bnr, nunet_stream_t s) {
   int rc = ew_check("maxpool_bwd", dtype, N, H, W, C, PX, PDX);
   if (rc) return rc;
   NUNET_REQUIRE(x && dy && dx && H % 2 == 0 && W % 2 == 0 && PDY % (16 / dtype_size(dtype)) == 0, "maxpool_bwd: bad args");
-  return NUNET_DISPATCH(dtype, launch_maxpool_bwd, N, H, W, C, x, PX, dy, PDY, dx, PDX, accumulate, (hipStream_t)s);
+  return NUNET_DISPATCH(dtype, launch_maxpool_bwd, N, H, W, C, x, PX, dy, PDY, dx, PDX, accumulate, bnr, (hipStream_t)s);
+}
+extern "C" int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
+  return nunet_maxpool2x2_bwd_bnr(dtype, N, H, W, C, x, PX, dy, PDY, dx, PDX, accumulate, nullptr, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -578,10 +651,13 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
   }
 }
 // gather form of the transposed interpolation: one thread per low-res pixel
-template <typename T>
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc) {
+template <typename T, bool BNR>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc, BnrP bn) {
   constexpr int EPV = Tr<T>::EPV;
   const int G = C / EPV, HO = 2 * H, WO = 2 * W;
+  __shared__ float s_part[BNR ? 256 * 2 * EPV : 1];
+  BnrAcc<T> ba;
+  if constexpr (BNR) ba.init(bn, threadIdx.x % G);
   const float sy = HO > 1 ? (float)(H - 1) / (float)(HO - 1) : 0.f;
   const float sx = WO > 1 ? (float)(W - 1) / (float)(WO - 1) : 0.f;
   const int64_t total = (int64_t)N * H * W * G;
@@ -653,7 +729,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < EPV; ++e) r.set(e, (accumulate ? r.get(e) : 0.f) + acc[e]);
     st16(q, r);
+    if constexpr (BNR) ba.add(bn, cg, o, r);
   }
+  if constexpr (BNR) ba.finish(bn, s_part, G);
 }
 template <typename T> static int launch_up_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * 4 * H * W * (C / Tr<T>::EPV);
@@ -661,10 +739,17 @@ template <typename T> static int launch_up_fwd(int N, int H, int W, int C, const
   NUNET_LAUNCH((upsample_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, 2 * W, 2 * H));
   return nunet_check_launch("upsample_fwd");
 }
-template <typename T> static int launch_up_bwd(int N, int H, int W, int C, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
+template <typename T> static int launch_up_bwd(int N, int H, int W, int C, const void* dy, int PDY, void* dx, int PDX, int acc, const nunet_bnr_desc* bnr, hipStream_t st) {
   const int64_t total = (int64_t)N * H * W * (C / Tr<T>::EPV);
-  ProfScope ps(PC_UP_BWD, 0, (double)N * H * W * C * sizeof(T) * (acc ? 6.0 : 5.0), st);
-  NUNET_LAUNCH((upsample_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H));
+  ProfScope ps(PC_UP_BWD, 0, (double)N * H * W * C * sizeof(T) * ((acc ? 6.0 : 5.0) + (bnr ? 1.0 : 0.0)), st);
+  BnrP b; memset(&b, 0, sizeof(b));
+  if (bnr) {
+    NUNET_REQUIRE(256 % (C / Tr<T>::EPV) == 0, "upsample_bwd: fused BN reduce needs C / %d to divide 256", Tr<T>::EPV);
+    int rc = bnr_fill(b, bnr, C, Tr<T>::DT); if (rc) return rc;
+    // (fewer, fatter blocks: every block ends with 2C fixed-point adds)
+    NUNET_LAUNCH((upsample_bwd_kernel<T, true>), dim3(grid_for(total, 256 * 2, 1024)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H), b);
+  } else
+    NUNET_LAUNCH((upsample_bwd_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H), b);
   return nunet_check_launch("upsample_bwd");
 }
 extern "C" int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s) {
@@ -673,11 +758,14 @@ extern "C" int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t
   NUNET_REQUIRE(x && y, "upsample_fwd: null pointer");
   return NUNET_DISPATCH(dtype, launch_up_fwd, N, H, W, C, x, PX, y, PY, (hipStream_t)s);
 }
-extern "C" int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
+extern "C" int nunet_upsample2x_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, const nunet_bnr_desc* bnr, nunet_stream_t s) {
   int rc = ew_check("upsample_bwd", dtype, N, H, W, C, PDY, PDX);
   if (rc) return rc;
   NUNET_REQUIRE(dy && dx, "upsample_bwd: null pointer");
-  return NUNET_DISPATCH(dtype, launch_up_bwd, N, H, W, C, dy, PDY, dx, PDX, accumulate, (hipStream_t)s);
+  return NUNET_DISPATCH(dtype, launch_up_bwd, N, H, W, C, dy, PDY, dx, PDX, accumulate, bnr, (hipStream_t)s);
+}
+extern "C" int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
+  return nunet_upsample2x_bwd_bnr(dtype, N, H, W, C, dy, PDY, dx, PDX, accumulate, nullptr, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -713,8 +801,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
       if (k < K) logits[((int64_t)n * K + k) * hw + rem] = acc[k] + b[k];
   }
 }
-template <typename T, int KT>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int PX, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx, int PDX, int accumulate, float* __restrict__ dw, int N, int H, int W, int C, int K) {
+template <typename T, int KT, bool BNR>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int PX, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx, int PDX, int accumulate, float* __restrict__ dw, int N, int H, int W, int C, int K, BnrP bn) {
   // C == 32. A thread owns one 16-byte channel group (EPV channels) of a pixel; G = 32/EPV threads
   // cover a pixel. dW/db partials live in registers (KT = compile-time class count, 0 = generic)
   // and meet through LDS once per block.
@@ -723,6 +811,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   constexpr int KM = KT > 0 ? KT : HEAD_MAXK;
   __shared__ float s_dw[4 * (HEAD_MAXK * 32 + HEAD_MAXK)];   // per wave
   const int cg = threadIdx.x % G, pl = threadIdx.x / G, ppb = blockDim.x / G;
+  __shared__ float s_part[BNR ? 256 * 2 * EPV : 1];
+  BnrAcc<T> ba;
+  if constexpr (BNR) ba.init(bn, cg);
   float wk[KM][EPV], aw[KM][EPV], ab[KM];
 #pragma unroll
   for (int k = 0; k < KM; ++k) {
@@ -771,6 +862,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
 #pragma unroll
           for (int e = 0; e < EPV; ++e) o.set(e, (accumulate ? ov[u].get(e) : 0.f) + g[e]);
           st16(dx + pix * PDX + cg * EPV, o);
+          if constexpr (BNR) ba.add(bn, cg, pix, o);
         }
       }
     }
@@ -801,17 +893,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
     const int j = i < K * 32 ? i : HEAD_MAXK * 32 + (i - K * 32);
     slab[i] = (s_dw[j] + s_dw[HEAD_MAXK * 33 + j]) + (s_dw[2 * HEAD_MAXK * 33 + j] + s_dw[3 * HEAD_MAXK * 33 + j]);
   }
+  if constexpr (BNR) ba.finish(bn, s_part, G);
 }
 template <typename T> static int launch_head_fwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* b, float* logits, hipStream_t st) {
   ProfScope ps(PC_HEAD, 2.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) + K * 4), st);
   NUNET_LAUNCH((head_fwd_kernel<T>), dim3(grid_for((int64_t)N * H * W, 256)), dim3(256), 0, st, (const T*)x, PX, w, b, logits, N, H, W, C, K);
   return nunet_check_launch("head_fwd");
 }
-template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw_slabs, int nslabs, hipStream_t st) {
-  ProfScope ps(PC_HEAD, 4.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) * (acc ? 3 : 2) + K * 4), st);
+template <typename T> static int launch_head_bwd(int N, int H, int W, int C, int K, const void* x, int PX, const float* w, const float* dl, void* dx, int PDX, int acc, float* dw_slabs, int nslabs, const nunet_bnr_desc* bnr, hipStream_t st) {
+  ProfScope ps(PC_HEAD, 4.0 * N * H * W * C * K, (double)N * H * W * (C * sizeof(T) * ((acc ? 3 : 2) + (bnr ? 1 : 0)) + K * 4), st);
   const dim3 grid(nslabs), blk(256);
-#define NUNET_HB(KT) NUNET_LAUNCH((head_bwd_kernel<T, KT>), grid, blk, 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw_slabs, N, H, W, C, K)
-  if (K == 1) NUNET_HB(1); else if (K == 2) NUNET_HB(2); else if (K == 4) NUNET_HB(4); else NUNET_HB(0);
+  BnrP b; memset(&b, 0, sizeof(b));
+  if (bnr) { NUNET_REQUIRE(dx, "head_bwd: fused BN reduce needs dx"); int rc = bnr_fill(b, bnr, C, Tr<T>::DT); if (rc) return rc; }
+#define NUNET_HB(KT, BN_) NUNET_LAUNCH((head_bwd_kernel<T, KT, BN_>), grid, blk, 0, st, (const T*)x, PX, w, dl, (T*)dx, PDX, acc, dw_slabs, N, H, W, C, K, b)
+  if (bnr) { if (K == 1) NUNET_HB(1, true); else if (K == 2) NUNET_HB(2, true); else if (K == 4) NUNET_HB(4, true); else NUNET_HB(0, true); }
+  else { if (K == 1) NUNET_HB(1, false); else if (K == 2) NUNET_HB(2, false); else if (K == 4) NUNET_HB(4, false); else NUNET_HB(0, false); }
 #undef NUNET_HB
   return nunet_check_launch("head_bwd");
 }
@@ -821,11 +917,14 @@ extern "C" int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, in
   NUNET_REQUIRE(PX % (16 / dtype_size(dtype)) == 0, "head_fwd: pitch");
   return NUNET_DISPATCH(dtype, launch_head_fwd, N, H, W, C, K, x, PX, w, b, logits, (hipStream_t)s);
 }
-extern "C" int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* dlogits, void* dx, int32_t PDX, int32_t accumulate, float* dw_slabs, int32_t nslabs, nunet_stream_t s) {
+extern "C" int nunet_head_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* dlogits, void* dx, int32_t PDX, int32_t accumulate, float* dw_slabs, int32_t nslabs, const nunet_bnr_desc* bnr, nunet_stream_t s) {
   NUNET_REQUIRE(x && w && dlogits && dw_slabs && nslabs >= 1 && nslabs <= 4096, "head_bwd: bad args");
   NUNET_REQUIRE(C == 32 && K >= 1 && K <= HEAD_MAXK, "head_bwd: C=%d K=%d unsupported (C==32, K<=%d)", C, K, HEAD_MAXK);
   NUNET_REQUIRE((int64_t)N * H * W < (1LL << 31), "head_bwd: too many pixels");
-  return NUNET_DISPATCH(dtype, launch_head_bwd, N, H, W, C, K, x, PX, w, dlogits, dx, PDX, accumulate, dw_slabs, nslabs, (hipStream_t)s);
+  return NUNET_DISPATCH(dtype, launch_head_bwd, N, H, W, C, K, x, PX, w, dlogits, dx, PDX, accumulate, dw_slabs, nslabs, bnr, (hipStream_t)s);
+}
+extern "C" int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int32_t PX, const float* w, const float* dlogits, void* dx, int32_t PDX, int32_t accumulate, float* dw_slabs, int32_t nslabs, nunet_stream_t s) {
+  return nunet_head_bwd_bnr(dtype, N, H, W, C, K, x, PX, w, dlogits, dx, PDX, accumulate, dw_slabs, nslabs, nullptr, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -1313,6 +1313,31 @@ static int launch_reduce(nunet_plan* P, void* arena, int k_lo, int k_hi, hipStre
   return nunet_check_launch("wgrad slab reduce");
 }
 
+// Which op COMPLETES the gradient of block output x_{l,s} (slot s of GX_l)? Writers: a head (level 0), the dgrad of conv1
+// of a block of level l whose concat holds slot s, the upsample-backward of the level l-1 block that upsampled it, the
+// pool-backward of the level l+1 encoder block (slot 0). Ops are issued heads first, then blocks for k descending, and
+// writers of one slot are serialised in that order by the lane scheduler - so the last writer is the block writer with
+// the smallest k (or the head when no block writes the slot). It takes the BatchNorm-backward reduce of x_{l,s}'s block
+// in its epilogue when it is a head / upsample-backward / pool-backward (nunet_*_bwd_bnr); conv dgrads (three level-0
+// blocks of the nested net) leave it to the stand-alone reduce.
+enum { LW_NONE = 0, LW_HEAD, LW_DGRAD, LW_UPB, LW_POOLB };
+static void last_writer(const nunet_plan* P, int l, int s, int& kind, int& kk) {
+  kind = LW_NONE; kk = 1 << 30;
+  for (size_t h = 0; h < P->heads.size(); ++h) if (l == 0 && P->heads[h].slot == s) { kind = LW_HEAD; kk = 1 << 29; }
+  for (int k = (int)P->exec.size() - 1; k >= 0; --k) {
+    const Node& n = P->exec[k];
+    int w = LW_NONE;
+    if (n.i == l && n.in_prefix > s && !(n.i == 0 && n.in_prefix == 0)) w = LW_DGRAD;
+    if (n.i + 1 == l && n.in_prefix > 0 && n.up_slot == s) w = LW_UPB;
+    if (n.i - 1 == l && n.in_prefix == 0 && n.i > 0 && s == 0) w = LW_POOLB;
+    if (w != LW_NONE && k < kk) { kind = w; kk = k; }
+  }
+}
+static int block_of_slot(const nunet_plan* P, int l, int s) {
+  for (size_t k = 0; k < P->exec.size(); ++k) if (P->exec[k].i == l && P->exec[k].out_slot == s) return (int)k;
+  return -1;
+}
+
 // phases: 1 = heads and the last anti-diagonal's blocks (75 % of the gradient bytes);
 //         2 = the remaining blocks; 4 = unpack into the flat OIHW gradient arena. 7 = everything.
 extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s) {
@@ -1334,14 +1359,33 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   Sched S; S.init(P, st, 1);
   int rc = NUNET_OK;
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
+  static int fuse_bnr = -1;
+  if (fuse_bnr < 0) { const char* e = getenv("NUNET_FUSE_BNR"); fuse_bnr = e ? atoi(e) : 1; }
+  // reduce pass of block kt's second BatchNorm, for the kernel that completes its output gradient
+  auto bnr_of = [&](int kt) {
+    const Node& t = P->exec[kt];
+    nunet_bnr_desc b; memset(&b, 0, sizeof(b));
+    b.y = AB(arena, t.y2); b.PY = NBF[t.i]; b.mean_invstd = save + t.c2.save;
+    b.gamma = params + t.c2.g_off; b.beta = params + t.c2.be_off; b.sums = (int64_t*)fx_of(arena, P, 1, t.c2.bsum);
+    return b;
+  };
+  auto completes = [&](int l, int sl, int kind, int k) {      // does op (kind, block k) complete x_{l,sl}'s gradient?
+    if (!fuse_bnr) return -1;
+    int lk, lkk; last_writer(P, l, sl, lk, lkk);
+    if (lk != kind || (kind != LW_HEAD && lkk != k)) return -1;
+    return block_of_slot(P, l, sl);
+  };
   for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK && (phases & 1); ++k) {
     const Head& h = P->heads[k];
     const int acc = written[0][h.slot] ? 1 : 0;
+    const int kt = completes(0, h.slot, LW_HEAD, -1);
+    nunet_bnr_desc bd; memset(&bd, 0, sizeof(bd));
+    if (kt >= 0) bd = bnr_of(kt);
     S.name("head%d.B", (int)k);
-    S.add(0, 0, 0.f, {R_X + h.slot, R_DLOGITS}, {R_GX + h.slot, R_GSV + 30 + (int)k}, [=](hipStream_t ls) {
-      return nunet_head_bwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
-                            params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
-                            acc, gsr + h.gs, HEAD_SLABS, ls);
+    S.add(0, 0, 0.f, {R_X + h.slot, R_DLOGITS, kt >= 0 ? R_BLK + kt * B_STRIDE + B_Y2 : -1}, {R_GX + h.slot, R_GSV + 30 + (int)k, kt >= 0 ? R_GSV + 2 * kt + 1 : -1}, [=](hipStream_t ls) {
+      return nunet_head_bwd_bnr(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
+                                params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
+                                acc, gsr + h.gs, HEAD_SLABS, kt >= 0 ? &bd : nullptr, ls);
     });
     written[0][h.slot] = true;
   }
@@ -1379,8 +1423,14 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     b2.da = AB(arena, P->GX[i] + (size_t)n.out_slot * f * es); b2.PDA = P->PX[i]; b2.y = AB(arena, n.y2); b2.PY = f;
     b2.mean_invstd = save + L2.save; b2.gamma = params + L2.g_off; b2.beta = params + L2.be_off;
     b2.sums = (int64_t*)fx_of(arena, P, 1, L2.bsum);
-    S.name("B%d%d.bnR2", n.i, n.j);
-    S.add(lane, 0, 0.f, {r_gxo, rb + B_Y2}, {r_v2}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_reduce(&b2, ls); });
+    {
+      int lk, lkk; last_writer(P, i, n.out_slot, lk, lkk);
+      const bool fused = fuse_bnr && (lk == LW_HEAD || lk == LW_UPB || lk == LW_POOLB);   // taken by the op that completed the gradient
+      if (!fused) {
+        S.name("B%d%d.bnR2", n.i, n.j);
+        S.add(lane, 0, 0.f, {r_gxo, rb + B_Y2}, {r_v2}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_reduce(&b2, ls); });
+      }
+    }
 
     // ---- dgrad of conv2: the APPLY pass of BatchNorm2's backward happens on the way into LDS (dy2 is stored on the
     // side for the weight gradient); the epilogue takes BatchNorm1's reduce pass on the da1 it stores (archs1.py:23-30)
@@ -1418,10 +1468,13 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
         S.add(lane, 0, 0.f, {r_da1, rb + B_Y1, r_v1, R_WP + i}, {r_dy1, rl + L_GPIN, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
         // through MaxPool2d(2,2) into x_{i-1,0}
         const int acc = written[i - 1][0] ? 1 : 0;
+        const int kt = completes(i - 1, 0, LW_POOLB, k);
+        nunet_bnr_desc bd; memset(&bd, 0, sizeof(bd));
+        if (kt >= 0) bd = bnr_of(kt);
         S.name("B%d%d.poolB", n.i, n.j);
-        S.add(lane, 0, 0.f, {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0}, [=](hipStream_t ls) {
-          return nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
-                                      AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], acc, ls);
+        S.add(lane, 0, 0.f, {rl + L_GPIN, R_X + (i - 1) * 5 + 0, kt >= 0 ? R_BLK + kt * B_STRIDE + B_Y2 : -1}, {R_GX + (i - 1) * 5 + 0, kt >= 0 ? R_GSV + 2 * kt + 1 : -1}, [=](hipStream_t ls) {
+          return nunet_maxpool2x2_bwd_bnr(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
+                                          AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], acc, kt >= 0 ? &bd : nullptr, ls);
         });
         written[i - 1][0] = true;
       } else {
@@ -1433,10 +1486,13 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
                n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
         // through the bilinear upsample into x_{i+1,up_slot}
         const int acc = written[i + 1][n.up_slot] ? 1 : 0;
+        const int kt = completes(i + 1, n.up_slot, LW_UPB, k);
+        nunet_bnr_desc bd; memset(&bd, 0, sizeof(bd));
+        if (kt >= 0) bd = bnr_of(kt);
         S.name("B%d%d.upB", n.i, n.j);
-        S.add(lane, 0, 0.f, {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot}, [=](hipStream_t ls) {
-          return nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
-                                      AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], acc, ls);
+        S.add(lane, 0, 0.f, {rl + L_GUP, kt >= 0 ? R_BLK + kt * B_STRIDE + B_Y2 : -1}, {R_GX + (i + 1) * 5 + n.up_slot, kt >= 0 ? R_GSV + 2 * kt + 1 : -1}, [=](hipStream_t ls) {
+          return nunet_upsample2x_bwd_bnr(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
+                                          AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], acc, kt >= 0 ? &bd : nullptr, ls);
         });
         written[i + 1][n.up_slot] = true;
       }
@@ -1472,14 +1528,12 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       int rx[4] = {-1, -1, -1, -1}, r_in = -1, r_up = -1;
       if (n.in_prefix == 0) r_in = (i == 0 ? R_IMG : rb + B_PIN);
       else { for (int q = 0; q < n.in_prefix && q < 4; ++q) rx[q] = R_X + i * 5 + q; r_up = rb + B_UP; }
-      static int abl = -1; if (abl < 0) { const char* e = getenv("NUNET_ABLATE"); abl = e ? atoi(e) : 0; }   /* ABLATE-DIAG */
       // The weight gradients of the shallow blocks of the critical chain (B04, B13, B22: full-chip launches) are held
       // back until the chain reaches the deep levels (B31 ..., grid-starved kernels that leave most CUs idle): they run
       // on lane 4 behind a dependency on the gradient that B22's upsample-backward hands to B31
-      static int defer = -1; if (defer < 0) { const char* e = getenv("NUNET_WG_DEFER"); defer = e ? atoi(e) : 0; }
+      static int defer = -1; if (defer < 0) { const char* e = getenv("NUNET_WG_DEFER"); defer = e ? atoi(e) : 1; }   // measured +1.9 %
       int wl = wlane, r_gate = -1;
       if (defer && !P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
-      if (!(abl & 1))   /* ABLATE-DIAG */
       S.add(wl, 1, 0.f, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up, r_gate}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
             [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w1, &w2, ls); g_prof_alg_cin = 0; return r; });
     }
@@ -1515,7 +1569,6 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   // slab sums of the nodes this call covered (phase-1 nodes were already reduced inside the pass when bucket 0 is signalled there)
   if (phases & 3) {
     const int lo = k_lo, hi = (b0_inside && S.multi) ? k_split - 1 : k_hi;
-    { const char* e = getenv("NUNET_ABLATE"); if (e && (atoi(e) & 2)) return NUNET_OK; }   /* ABLATE-DIAG */
     if (hi >= lo) CK(launch_reduce(P, arena, lo, hi, st));
   }
   if (!(phases & 4)) return NUNET_OK;

@@ -429,6 +429,78 @@ def test_head(dt, k):
     assert rel_err(tot[k * c:], bd.grad) < 1e-4
 
 
+def _bnr_setup(n, h, w, c, dt, g):
+    """A BatchNorm whose backward reduce is fused into the kernel that completes its output gradient."""
+    y = q(torch.randn(n, c, h, w, generator=g), dt)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(DEV)
+    beta = (0.2 * torch.randn(c, generator=g)).to(DEV)
+    mean = y.double().mean((0, 2, 3))
+    istd = 1 / (y.double().var((0, 2, 3), unbiased=False) + 1e-5).sqrt()
+    mi = torch.cat([mean, istd]).float().to(DEV)
+    yb = nhwc(y, dt)
+    sums = L.fx_zeros(c, DEV)
+    d = L.BnrDesc(L.ptr(yb), c, L.ptr(mi), L.ptr(gamma), L.ptr(beta), L.ptr(sums))
+    return d, sums, (yb, mi, gamma, beta)
+
+
+def _bnr_check(dt, n, h, w, c, da_ptr, pda, sums, keep):
+    """The fused sums equal nunet_bn_relu_bwd_reduce run on the completed gradient tensor."""
+    yb, mi, gamma, beta = keep
+    ref = L.fx_zeros(c, DEV)
+    dummy = torch.zeros(c, dtype=torch.float32, device=DEV)
+    b = L.BnBwdDesc(dt, n, h, w, c, da_ptr, pda, L.ptr(yb), c, L.ptr(mi), L.ptr(gamma), L.ptr(beta), L.ptr(ref),
+                    L.ptr(dummy), L.ptr(dummy), L.ptr(dummy), None, 0)
+    L.check(L.lib().nunet_bn_relu_bwd_reduce(C.byref(b), L.stream()), "reduce")
+    torch.cuda.synchronize()
+    tot, rtot = L.fx_decode(sums, c), L.fx_decode(ref, c)
+    assert float(rtot.abs().max()) > 0
+    assert float((tot - rtot).abs().max()) < 2e-4 * float(rtot.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
+@pytest.mark.parametrize("acc", [0, 1])
+def test_fused_bn_reduce_in_upsample_pool_head_bwd(dt, acc):
+    """nunet_upsample2x_bwd_bnr / nunet_maxpool2x2_bwd_bnr / nunet_head_bwd_bnr: same gradients as the plain kernels,
+    plus the BatchNorm-backward sums of the tensor they complete."""
+    g = torch.Generator().manual_seed(41 + acc)
+    # upsample backward: low-res gradient [n, c, h, w] in a slot of a wider buffer
+    n, c, h, w = 3, 64, 12, 10
+    dy = nhwc(q(torch.randn(n, c, 2 * h, 2 * w, generator=g), dt), dt)
+    prev = q(torch.randn(n, c, h, w, generator=g), dt)
+    es = 4 if dt == L.F32 else 2
+    d, sums, keep = _bnr_setup(n, h, w, c, dt, g)
+    a = nhwc(prev, dt, pitch=192, off=64); b_ = nhwc(prev, dt, pitch=192, off=64)
+    L.check(L.lib().nunet_upsample2x_bwd(dt, n, h, w, c, L.ptr(dy), c, L.ptr(a, 64 * es), 192, acc, L.stream()), "up")
+    L.check(L.lib().nunet_upsample2x_bwd_bnr(dt, n, h, w, c, L.ptr(dy), c, L.ptr(b_, 64 * es), 192, acc, C.byref(d), L.stream()), "up bnr")
+    assert torch.equal(a, b_)
+    _bnr_check(dt, n, h, w, c, L.ptr(b_, 64 * es), 192, sums, keep)
+    # pool backward: high-res gradient [n, c, 2h, 2w]
+    x = nhwc(q(torch.randn(n, c, 2 * h, 2 * w, generator=g), dt), dt)
+    dyp = nhwc(q(torch.randn(n, c, h, w, generator=g), dt), dt)
+    prevh = q(torch.randn(n, c, 2 * h, 2 * w, generator=g), dt)
+    d, sums, keep = _bnr_setup(n, 2 * h, 2 * w, c, dt, g)
+    a, b_ = nhwc(prevh, dt), nhwc(prevh, dt)
+    L.check(L.lib().nunet_maxpool2x2_bwd(dt, n, 2 * h, 2 * w, c, L.ptr(x), c, L.ptr(dyp), c, L.ptr(a), c, acc, L.stream()), "pool")
+    L.check(L.lib().nunet_maxpool2x2_bwd_bnr(dt, n, 2 * h, 2 * w, c, L.ptr(x), c, L.ptr(dyp), c, L.ptr(b_), c, acc, C.byref(d), L.stream()), "pool bnr")
+    assert torch.equal(a, b_)
+    _bnr_check(dt, n, 2 * h, 2 * w, c, L.ptr(b_), c, sums, keep)
+    # head backward: 32 channels, slot of the level-0 buffer
+    k, c = 2, 32
+    xh = nhwc(q(torch.randn(n, c, h, w, generator=g), dt), dt, pitch=160, off=128)
+    wt = (torch.randn(k, c, generator=g) * 0.2).to(DEV)
+    dl = torch.randn(n, k, h, w, generator=g).to(DEV)
+    prev32 = q(torch.randn(n, c, h, w, generator=g), dt)
+    d, sums, keep = _bnr_setup(n, h, w, c, dt, g)
+    a, b_ = nhwc(prev32, dt, pitch=160, off=128), nhwc(prev32, dt, pitch=160, off=128)
+    s1 = torch.zeros((64, k * c + k), dtype=torch.float32, device=DEV); s2 = torch.zeros_like(s1)
+    L.check(L.lib().nunet_head_bwd(dt, n, h, w, c, k, L.ptr(xh, 128 * es), 160, L.ptr(wt), L.ptr(dl), L.ptr(a, 128 * es), 160, acc,
+                                   L.ptr(s1), 64, L.stream()), "head")
+    L.check(L.lib().nunet_head_bwd_bnr(dt, n, h, w, c, k, L.ptr(xh, 128 * es), 160, L.ptr(wt), L.ptr(dl), L.ptr(b_, 128 * es), 160, acc,
+                                       L.ptr(s2), 64, C.byref(d), L.stream()), "head bnr")
+    assert torch.equal(a, b_) and torch.equal(s1, s2)
+    _bnr_check(dt, n, h, w, c, L.ptr(b_, 128 * es), 160, sums, keep)
+
+
 def test_bce_dice_and_iou_against_reference_goldens():
     from conftest import load_golden
     g = load_golden("small_ops")
