@@ -975,55 +975,87 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
   }
   __syncthreads();
 
-  // tile-invariant staging codes of this thread's units (-2: no such unit)
-  int dcode[C::NUD], acode[C::NUA];
+  // Tile-invariant part of every staging unit's address, computed ONCE: in-kernel cycle stamps (tools/wgrad_stamps.py)
+  // showed the per-tile address generation (seven map_pixel() calls with 64-bit pointer arithmetic per thread) at
+  // 2300 cycles - more than the tile's MFMAs and fragment reads together (1300-2100). A unit is (image-in-tile ni,
+  // row dy, column dx) relative to the tile origin: its pixel is gp0(tile) + uoff, its validity two or three compares,
+  // its address a 32-bit byte offset from a uniform base (host-checked to fit). Units outside the image read pixel 0
+  // and are zeroed on the way into LDS.
+  //   code: (ni << 20) | ((dy + 1) << 10) | (dx + 1) with dy, dx >= -1;  -2: no such unit
+  int dcode[C::NUD], acode[C::NUA], duoff[C::NUD], auoff[C::NUA];
 #pragma unroll
-  for (int k = 0; k < C::NUD; ++k) { const int u = tid + k * NT; dcode[k] = u < BM * UPP ? s_mxy[u / UPP] : -2; }
+  for (int k = 0; k < C::NUD; ++k) {
+    const int u = tid + k * NT;
+    const int cde = u < BM * UPP ? s_mxy[u / UPP] : -2;                 // (ni, ly, lx), -1: row past the tile
+    dcode[k] = cde >= 0 ? cde + (1 << 10) + 1 : cde;
+    duoff[k] = cde >= 0 ? ((cde >> 20) * p.H + ((cde >> 10) & 1023)) * p.W + (cde & 1023) : 0;
+  }
 #pragma unroll
-  for (int k = 0; k < C::NUA; ++k) { const int u = tid + k * NT; acode[k] = u < C::HPMAX * UPP ? s_hxy[u / UPP] : -2; }
+  for (int k = 0; k < C::NUA; ++k) {
+    const int u = tid + k * NT;
+    const int cde = u < C::HPMAX * UPP ? s_hxy[u / UPP] : -2;           // (ni, hy, hx): halo coordinates = tile coordinates + 1
+    acode[k] = cde;
+    auoff[k] = cde >= 0 ? ((cde >> 20) * p.H + ((cde >> 10) & 1023) - 1) * p.W + (cde & 1023) - 1 : 0;
+  }
   // the channel slice of the forward input this item reads: one source per 16-byte unit
   // (C0 is a multiple of 16, so a unit never straddles the two concat sources)
   const int seg = tid % UPP;                 // same for all units of a thread (NT % UPP == 0)
   const int cch = ci0 + seg * EPV;
   const bool cvalid = cch < p.Cin;
-  const T* asrc; int apitch, ach;
-  if (cch < p.C0) { asrc = (const T*)p.src0; apitch = p.P0; ach = cch; }
-  else { asrc = (const T*)p.src1; apitch = p.P1; ach = cch - p.C0; }
-  const T* dsrc = (const T*)p.dy + co0 + seg * EPV;
+  const char* abase; unsigned apb, acb;      // uniform base, pitch in bytes, this thread's channel byte offset
+  if (cch < p.C0) { abase = (const char*)p.src0; apb = (unsigned)p.P0 * (unsigned)sizeof(T); acb = (unsigned)cch * (unsigned)sizeof(T); }
+  else { abase = (const char*)p.src1; apb = (unsigned)p.P1 * (unsigned)sizeof(T); acb = (unsigned)(cch - p.C0) * (unsigned)sizeof(T); }
+  const char* const dbase = (const char*)p.dy;
+  const unsigned dpb = (unsigned)p.PY * (unsigned)sizeof(T), dcb = (unsigned)(co0 + seg * EPV) * (unsigned)sizeof(T);
 
   Vec16<T> dreg[C::NUD], areg[C::NUA];
+  unsigned vmask = 0u;                       // bit k: dY unit k valid; bit 8 + k: input unit k valid (of the tile held in the registers)
+  // pixel of a unit (code, uoff) of the tile at (n0, y0, x0); -1: outside the image
+  auto unit_pixel = [&](int code, int uoff, int n0, int y0, int x0, int gp0) {
+    const int ni = code >> 20, dy = ((code >> 10) & 1023) - 1, dx = (code & 1023) - 1;
+    if constexpr (ST) {
+      // stacked rows: virtual row v = y0 + dy of ONE image of N * SH rows; rows with v % SH == 0 separate the images
+      const int v = y0 + dy, x = dx;
+      const int vc = v < 0 ? 0 : v;
+      const int n2 = (int)__umulhi((unsigned)vc, p.SHinv), yy = vc - n2 * p.SH - 1;
+      const bool ok = (v >= 0) & (yy >= 0) & (n2 < p.N) & (x >= 0) & (x < p.W);
+      return ok ? (n2 * p.H + yy) * p.W + x : -1;
+    } else {
+      const int y = y0 + dy, x = x0 + dx;
+      const bool ok = (n0 + ni < p.N) & (y >= 0) & (y < p.H) & (x >= 0) & (x < p.W);
+      return ok ? gp0 + uoff : -1;
+    }
+  };
   auto load_tile = [&](int mt) {
     const int q1 = fastdiv(mt, p.invTX), q2 = fastdiv(q1, p.invTY);
     const int x0 = (mt - q1 * p.tilesX) * p.TW;
     const int y0 = (q1 - q2 * p.tilesY) * p.TH;
     const int n0 = q2 * p.NI;
-    // branch-free: a unit outside the image (or past the tile / channel range) reads a page of zeros, so the seven
-    // loads of a tile are independent instructions of one basic block instead of seven guarded blocks
-    const T* const zp = reinterpret_cast<const T*>(g_zero_page);
+    const int gp0 = (n0 * p.H + y0) * p.W + x0;
+    unsigned vm = 0u;
 #pragma unroll
     for (int k = 0; k < C::NUD; ++k) {
-      const int cde = dcode[k] >= 0 ? dcode[k] : 0;
-      const int n = n0 + (cde >> 20), y = y0 + ((cde >> 10) & 1023), x = x0 + (cde & 1023);
-      int gp = map_pixel_t<ST>(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
-      if (dcode[k] < 0) gp = -1;
-      dreg[k] = ld16(gp >= 0 ? dsrc + (size_t)gp * p.PY : zp);
+      const int gp = dcode[k] >= 0 ? unit_pixel(dcode[k], duoff[k], n0, y0, x0, gp0) : -1;
+      vm |= gp >= 0 ? (1u << k) : 0u;
+      dreg[k].raw = *reinterpret_cast<const u32x4*>(dbase + ((unsigned)(gp < 0 ? 0 : gp) * dpb + dcb));
     }
 #pragma unroll
     for (int k = 0; k < C::NUA; ++k) {
-      const int cde = acode[k] >= 0 ? acode[k] : 0;
-      const int n = n0 + (cde >> 20), y = y0 + ((cde >> 10) & 1023) - 1, x = x0 + (cde & 1023) - 1;
-      int gp = map_pixel_t<ST>(n, y, x, p.N, p.H, p.W, p.SH, p.SHinv);
-      if (acode[k] < 0 || !cvalid) gp = -1;
-      areg[k] = ld16(gp >= 0 ? asrc + (size_t)gp * apitch + ach : zp);
+      const int gp = (acode[k] >= 0 && cvalid) ? unit_pixel(acode[k], auoff[k], n0, y0, x0, gp0) : -1;
+      vm |= gp >= 0 ? (1u << (8 + k)) : 0u;
+      areg[k].raw = *reinterpret_cast<const u32x4*>(abase + ((unsigned)(gp < 0 ? 0 : gp) * apb + acb));
     }
+    vmask = vm;
   };
   auto write_tile = [&](int buf) {
     T* sd = s_stage + buf * C::STAGE;
     T* sa = sd + BM * SR;
 #pragma unroll
-    for (int k = 0; k < C::NUD; ++k) if ((k + 1) * NT <= BM * UPP || dcode[k] != -2) st16(&sd[((tid + k * NT) / UPP) * SR + seg * EPV], dreg[k]);
+    for (int k = 0; k < C::NUD; ++k)
+      if ((k + 1) * NT <= BM * UPP || dcode[k] != -2) st16(&sd[((tid + k * NT) / UPP) * SR + seg * EPV], (vmask >> k) & 1u ? dreg[k] : zero16<T>());
 #pragma unroll
-    for (int k = 0; k < C::NUA; ++k) if ((k + 1) * NT <= C::HPMAX * UPP || acode[k] != -2) st16(&sa[((tid + k * NT) / UPP) * SR + seg * EPV], areg[k]);
+    for (int k = 0; k < C::NUA; ++k)
+      if ((k + 1) * NT <= C::HPMAX * UPP || acode[k] != -2) st16(&sa[((tid + k * NT) / UPP) * SR + seg * EPV], (vmask >> (8 + k)) & 1u ? areg[k] : zero16<T>());
   };
 
   f32x16 acc[3];
@@ -1036,6 +1068,18 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
   int toff[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) toff[t] = ((wave - 1) * HW2 + (t - 1)) * SR;
+
+  // tile-invariant LDS offsets of this lane's fragment rows (16-bit types): A rows m = kk*16 + 8h + q (+4), B = their halo
+  // pixel shifted to this wave's kernel row, tap t at + t * SR
+  const int fq = (lane >> 2) & 3, colo = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int aoff = (8 * h + fq) * SR + colo;
+  int boff0[BM / 16], boff1[BM / 16];
+#pragma unroll
+  for (int kk = 0; kk < BM / 16; ++kk) {
+    const int m0 = kk * 16 + 8 * h + fq;
+    boff0[kk] = s_hidx[m0] * SR + colo + toff[0];
+    boff1[kk] = s_hidx[m0 + 4] * SR + colo + toff[0];
+  }
 
   int mt = split;
   if (mt < p.nMT) load_tile(mt);
@@ -1058,22 +1102,26 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sa[hx + toff[t]], acc[t], 0, 0, 0);
       }
     } else {
+      // fragments of k-step kk + 1 are read while k-step kk multiplies (two named register sets); the halo offsets of a
+      // lane's rows are tile-invariant and were hoisted out of the tile loop (boff): the k-step used to open with two
+      // LDS index reads and a full lgkmcnt(0) round trip before it could even form its addresses
       typedef typename Frag16<T>::V FV;
-      const int q = (lane >> 2) & 3;                             // row within the 4-row block
-      const int colo = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);  // column offset supplied by this lane
+      s16x4 fa0[2], fa1[2], fx0[2][3], fx1[2][3];
+      auto rd = [&](int kk, int sl) {
+        fa0[sl] = tr_read(&sd[aoff + kk * 16 * SR]);
+        fa1[sl] = tr_read(&sd[aoff + (kk * 16 + 4) * SR]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { fx0[sl][t] = tr_read(&sa[boff0[kk] + t * SR]); fx1[sl][t] = tr_read(&sa[boff1[kk] + t * SR]); }
+      };
+      rd(0, 0);
 #pragma unroll
       for (int kk = 0; kk < BM / 16; ++kk) {
-        const int m0 = kk * 16 + 8 * h + q, m1 = m0 + 4;
-        const int b0 = s_hidx[m0] * SR + colo, b1 = s_hidx[m1] * SR + colo;
-        const s16x4 a0 = tr_read(&sd[m0 * SR + colo]);
-        const s16x4 a1 = tr_read(&sd[m1 * SR + colo]);
-        const s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-        s16x4 x0[3], x1[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) { x0[t] = tr_read(&sa[b0 + toff[t]]); x1[t] = tr_read(&sa[b1 + toff[t]]); }
+        const int cu = kk & 1;
+        if (kk + 1 < BM / 16) rd(kk + 1, cu ^ 1);
+        const s16x8 av = __builtin_shufflevector(fa0[cu], fa1[cu], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          const s16x8 bv = __builtin_shufflevector(x0[t], x1[t], 0, 1, 2, 3, 4, 5, 6, 7);
+          const s16x8 bv = __builtin_shufflevector(fx0[cu][t], fx1[cu][t], 0, 1, 2, 3, 4, 5, 6, 7);
           Mma<T>::mma(acc[t], __builtin_bit_cast(FV, av), __builtin_bit_cast(FV, bv));
         }
       }
@@ -1192,6 +1240,10 @@ static int wgrad_check(const nunet_wgrad_desc* d) {
   const int epv = 16 / dtype_size(d->dtype);
   NUNET_REQUIRE(d->P0 % epv == 0 && (d->C1 == 0 || d->P1 % epv == 0) && d->PY % epv == 0, "wgrad: pitch alignment");
   NUNET_REQUIRE((long)d->N * d->H * d->W < (1L << 30), "wgrad: too many pixels");
+  {
+    const unsigned long long px = (unsigned long long)d->N * d->H * d->W, es = dtype_size(d->dtype), lim = 1ull << 32;   // 32-bit staging offsets
+    NUNET_REQUIRE(px * d->P0 * es < lim && (d->C1 == 0 || px * d->P1 * es < lim) && px * d->PY * es < lim, "wgrad: every input tensor must span < 4 GB");
+  }
   NUNET_REQUIRE(d->slab_stride == 0 || d->slab_stride >= 9LL * d->Cout * (d->C0 + d->C1), "wgrad: slab_stride smaller than one slab");
   NUNET_REQUIRE(d->max_slabs >= 0 && d->target_wgs >= 0, "wgrad: max_slabs / target_wgs");
   return NUNET_OK;
