@@ -268,8 +268,10 @@ int nunet_lovasz_hinge_bwd(const float* dlogits_unit, const float* gscale, int64
 /* counts[0] += |A&B|, counts[1] += |A|B|, A = logits>0, B = target>0.5 */
 int nunet_iou_counts(const float* logits, const float* target, int64_t n,
                      unsigned long long* counts, nunet_stream_t s);
-/* Mask export of the evaluation driver (reference val.py:100-105): out[i] = uint8(sigmoid(logits[i]) * 255). */
-int nunet_sigmoid_u8(const float* logits, uint8_t* out, int64_t n, nunet_stream_t stream);
+/* Mask export of the evaluation driver (reference val.py:100-105): out[i] = uint8(sigmoid(logits[i]) * 255), bit-exact
+ * against the reference's sigmoid: thresholds[k-1] (k = 1..255, fp32, device) = the smallest logit whose byte is >= k as
+ * the REFERENCE computes it (the caller derives them once by bisection with the reference's sigmoid); NaN maps to 0. */
+int nunet_sigmoid_u8(const float* logits, const float* thresholds, uint8_t* out, int64_t n, nunet_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* optim.SGD.step as configured at trains.py:229-231                         */

@@ -136,7 +136,7 @@ _SIG = {
     "nunet_lovasz_hinge_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
     "nunet_lovasz_hinge_bwd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "nunet_iou_counts": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "nunet_sigmoid_u8": (_i32, [_vp, _vp, _i64, _vp]),
+    "nunet_sigmoid_u8": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "nunet_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _i32, _f32, _vp]),
     "nunet_preprocess_u8": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
     "nunet_nchw_to_nhwc": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

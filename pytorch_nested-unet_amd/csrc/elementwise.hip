@@ -1157,27 +1157,40 @@ extern "C" int nunet_iou_counts(const float* logits, const float* target, int64_
 // Mask export of the evaluation driver: uint8(sigmoid(logit) * 255), truncating like numpy's astype('uint8')
 // (reference val.py:100-105: `(output[i, c] * 255).astype('uint8')` after torch.sigmoid)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sigmoid_u8_kernel(const float* __restrict__ logits, uint8_t* __restrict__ out, int64_t n) {
+// byte = number of thresholds <= x: thr[k-1] (k = 1..255) is the smallest fp32 logit whose reference byte is >= k, found
+// by the caller with the reference's own sigmoid (bisection over fp32 bit patterns, metrics.sigmoid_u8_thresholds), so
+// the byte matches `(torch.sigmoid(x) * 255).astype('uint8')` EXACTLY - a device expf one ulp away from the host's would
+// flip bytes whose sigmoid * 255 sits next to an integer. Branch-free 8-step binary search in LDS.
+__device__ __forceinline__ uint32_t sigmoid_byte(const float* s_thr, float x) {
+  int lo = 0;                                   // invariant: thr[lo-1] <= x (or lo == 0), answer in [lo, lo + span]
+#pragma unroll
+  for (int span = 128; span > 0; span >>= 1) {
+    const int mid = lo + span;                  // candidate count
+    if (mid <= 255 && s_thr[mid - 1] <= x) lo = mid;
+  }
+  return (uint32_t)lo;
+}
+__global__ __launch_bounds__(256) void sigmoid_u8_kernel(const float* __restrict__ logits, const float* __restrict__ thr, uint8_t* __restrict__ out, int64_t n) {
+  __shared__ float s_thr[256];
+  if (threadIdx.x < 255) s_thr[threadIdx.x] = thr[threadIdx.x];
+  __syncthreads();
   const int64_t n4 = n / 4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const f32x4 v = reinterpret_cast<const f32x4*>(logits)[i];
     uint32_t w = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float pr = 1.0f / (1.0f + expf(-v[e]));
-      w |= (uint32_t)(uint8_t)(pr * 255.0f) << (8 * e);
-    }
+    for (int e = 0; e < 4; ++e) w |= sigmoid_byte(s_thr, v[e]) << (8 * e);
     reinterpret_cast<uint32_t*>(out)[i] = w;
   }
   if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
     const int64_t i = n4 * 4 + threadIdx.x;
-    out[i] = (uint8_t)(255.0f / (1.0f + expf(-logits[i])));
+    out[i] = (uint8_t)sigmoid_byte(s_thr, logits[i]);
   }
 }
-extern "C" int nunet_sigmoid_u8(const float* logits, uint8_t* out, int64_t n, nunet_stream_t s) {
-  NUNET_REQUIRE(logits && out && n > 0, "sigmoid_u8: bad args");
+extern "C" int nunet_sigmoid_u8(const float* logits, const float* thresholds, uint8_t* out, int64_t n, nunet_stream_t s) {
+  NUNET_REQUIRE(logits && thresholds && out && n > 0, "sigmoid_u8: bad args");
   NUNET_REQUIRE(((uintptr_t)logits & 15) == 0 && ((uintptr_t)out & 3) == 0, "sigmoid_u8: logits must be 16-byte and out 4-byte aligned");
-  NUNET_LAUNCH(sigmoid_u8_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)s, logits, out, n);
+  NUNET_LAUNCH(sigmoid_u8_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)s, logits, thresholds, out, n);
   return nunet_check_launch("sigmoid_u8");
 }
 

@@ -71,6 +71,15 @@ def synth_blob_pairs(n, h, w, seed=1234, cin=3):
     return np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32), msk
 
 
+def synth_split(n, h, w, cin=3, ncls=1, seed=1000):
+    """Seeded dataset split of the drivers (train.py seed 1000, val.py / validation seed 2000). One class and three
+    channels: the learnable blob set (synth_blob_pairs, the set behind tests/golden/train_log_blobs.npz); other shapes:
+    independent noise images and blob masks (synth_batch)."""
+    if cin == 3 and ncls == 1:
+        return synth_blob_pairs(n, h, w, seed=seed)
+    return synth_batch(n, h, w, cin, ncls, seed=seed)
+
+
 # ---------------------------------------------------------------------------
 # model topology (reference finished/archs1.py:85-111,113-143)
 # ---------------------------------------------------------------------------

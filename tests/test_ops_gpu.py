@@ -806,15 +806,22 @@ def test_device_input_pipeline_matches_host_pipeline(synth):
     assert D.draw_augmentation(8).dtype == torch.int32
 
 
-@pytest.mark.parametrize("shape", [(2, 1, 8, 12), (1, 4, 5, 7), (3, 2, 96, 96)])
+@pytest.mark.parametrize("shape", [(2, 1, 8, 16), (1, 4, 16, 16), (3, 2, 96, 96)])
 def test_sigmoid_masks_u8(shape):
-    """Mask export of the evaluation driver (reference val.py:100-105): (sigmoid(x) * 255).astype('uint8')."""
-    from nunet_amd.metrics import sigmoid_masks_u8
+    """Mask export of the evaluation driver (reference val.py:100-105): (sigmoid(x) * 255).astype('uint8'), BYTE-EXACT
+    against the host expression: random logits plus every truncation edge (the 255 thresholds and their fp32 neighbours).
+    (Element counts are multiples of 16 so that the host's torch.sigmoid takes its vectorised path everywhere; its scalar
+    tail can differ from it by an ulp.)"""
+    from nunet_amd.metrics import sigmoid_masks_u8, sigmoid_u8_thresholds
     g = torch.Generator().manual_seed(9)
     x = torch.randn(*shape, generator=g) * 4
-    x.view(-1)[:4] = torch.tensor([-100.0, 100.0, 0.0, 20.0])
+    thr = sigmoid_u8_thresholds(torch.device(DEV)).cpu()
+    edges = torch.cat([thr, torch.nextafter(thr, torch.tensor(-1e9)), torch.nextafter(thr, torch.tensor(1e9)),
+                       torch.tensor([-100.0, 100.0, 0.0, -0.0, 20.0])])
+    flat = x.view(-1)
+    k = min(edges.numel(), flat.numel())
+    flat[:k] = edges[:k]
     got = sigmoid_masks_u8(x.to(DEV)).cpu()
-    ref = torch.from_numpy((torch.sigmoid(x).numpy() * 255).astype("uint8"))
-    d = (got.int() - ref.int()).abs()
-    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-3     # expf vs torch's exp: off-by-one at a truncation edge only
-    assert got.view(-1)[0] == 0 and got.view(-1)[1] == 255 and got.view(-1)[2] == 127
+    ref = torch.from_numpy((torch.sigmoid(x).numpy() * np.float32(255)).astype("uint8"))
+    assert torch.equal(got, ref), int((got != ref).sum())
+    assert int(ref.max()) == 255 and int(ref.min()) == 0

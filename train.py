@@ -68,12 +68,7 @@ def parse_args():
 
 
 def make_split(n, h, w, cin, ncls, seed):
-    """Seeded synthetic split. One class, three channels: the learnable blob set (images rendered from the masks,
-    the set behind tests/golden/train_log_blobs.npz); other shapes: independent noise images and blob masks."""
-    if cin == 3 and ncls == 1:
-        img, msk = nunet_amd.synth.synth_blob_pairs(n, h, w, seed=seed)
-    else:
-        img, msk = nunet_amd.synth.synth_batch(n, h, w, cin, ncls, seed=seed)
+    img, msk = nunet_amd.synth.synth_split(n, h, w, cin, ncls, seed)
     return torch.from_numpy(img), torch.from_numpy(msk)
 
 

@@ -32,7 +32,7 @@ def main():
     model.load_state_dict(torch.load('models/%s/model.pth' % config['name'], map_location='cpu'))
     model = model.cuda()
     model.eval()
-    img, msk = nunet_amd.synth.synth_batch(config['val_size'], config['input_h'], config['input_w'],
+    img, msk = nunet_amd.synth.synth_split(config['val_size'], config['input_h'], config['input_w'],
                                            config['input_channels'], config['num_classes'], seed=2000)
     x, t = torch.from_numpy(img), torch.from_numpy(msk)
     meter = AverageMeter()
