@@ -387,21 +387,16 @@ typedef struct {
 int nunet_profile_begin(void);
 int nunet_profile_end(nunet_prof_entry* out, int32_t max_entries, int32_t* n_out);
 /* ------------------------------------------------------------------------ */
-/* Lane-faithful hipGraph of a captured step (csrc/graph.hip).                 */
+/* hipGraph of a captured step (csrc/graph.hip).                               */
 /* Replaces, for this path, what the reference gets from eager PyTorch         */
 /* dispatch of trains.py:113-135: the step is captured once and replayed.      */
-/* begin/end bracket a stream capture on an explicit stream; end() rewrites    */
-/* the captured graph's edge lists so that ROCm's node->stream assignment      */
-/* reproduces the lanes the plan scheduled, then instantiates it.              */
+/* begin/end bracket a stream capture on an explicit stream; end()             */
+/* instantiates the graph with a launch stream (hardware queue) of its own.    */
 /* ------------------------------------------------------------------------ */
 typedef struct nunet_graph nunet_graph;
 int nunet_graph_begin(nunet_stream_t stream);
 int nunet_graph_end(nunet_stream_t stream, nunet_graph** out);
 int nunet_graph_launch(nunet_graph* graph, nunet_stream_t stream);
-/* Autotune: ROCm picks a node's stream from the ORDER of its parents' edge lists; the order has no
- * meaning, so random child swaps are timed (replays of the graph itself: the captured step runs
- * `iters * ~4 * replays` times, the caller restores its state afterwards) and kept when faster. */
-int nunet_graph_tune(nunet_graph* graph, int32_t iters, int32_t replays, uint32_t seed, float* base_ms, float* best_ms);
 int nunet_graph_info(const nunet_graph* graph, int32_t* nodes, int32_t* edges_captured, int32_t* edges_final, int32_t* padding, int32_t* lanes);
 void nunet_graph_destroy(nunet_graph* graph);
 

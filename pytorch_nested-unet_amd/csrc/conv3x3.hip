@@ -780,9 +780,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.nch0 = p.C0 / C::KC;
   p.nch = p.nch0 + p.C1 / C::KC;
   // (measured on the 96x96 workload, tools/conv_layers.py: below ~60 items a split pays for its finalize launch, above it does not)
-  static int sk_max_items = -1;
-  if (sk_max_items < 0) { const char* e = getenv("NUNET_SK_MAXITEMS"); sk_max_items = e ? atoi(e) : 60; }
-  if (d->splitk_ws && items <= sk_max_items && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
+  if (d->splitk_ws && items <= 60 && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
     int S = (int)((320 + items - 1) / items);
     if (S > p.nch / 2) S = p.nch / 2;
     const long long need = (long long)S * d->N * d->H * d->W * p.Cout;
@@ -829,20 +827,15 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
 
 template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream_t st) {
   const int cout = d->D0 + d->D1;
-  static int small_mode = -1;
-  if (small_mode < 0) { const char* e = getenv("NUNET_CONV_SMALL"); small_mode = e ? atoi(e) : 2; }
   // Tile choice (measured per layer on MI355X, tools/conv_layers.py): the standard tiles are 128 pixels x 64 channels
   // (Cout multiple of 64: 2 x 2 waves of 64 x 32) or 256 x 32. They leave a deep level (few pixels) with fewer work
   // items than the chip has CUs; there the 128 x 32 tile (4 workgroups per CU, twice the items) wins by up to 2x and
   // needs no K-split. It also wins for the plain / BN-forward Cout = 32 convs of the first level (one wave per SIMD
   // with the 256-pixel tile). With the BN-backward input transform the small tile loses: every Cout tile repeats the
   // transform of its input tile.
-  bool small = small_mode == 1;
-  if (small_mode == 2) {
-    const long px = (long)d->N * d->H * d->W;
-    const long items_std = cout % 64 == 0 ? ceil_div64(px, 128) * (cout / 64) : ceil_div64(px, 256) * (cout / 32);
-    small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD);
-  }
+  const long px = (long)d->N * d->H * d->W;
+  const long items_std = cout % 64 == 0 ? ceil_div64(px, 128) * (cout / 64) : ceil_div64(px, 256) * (cout / 32);
+  const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD);
   if (small) return launch_conv_cfg<T, 4, 1, 1, 1>(d, st);                              // 128 pixels x 32 channels
   if (cout % 64 == 0) return launch_conv_cfg<T, 2, 2, 2, 1>(d, st);
   return launch_conv_cfg<T, 4, 1, 2, 1>(d, st);

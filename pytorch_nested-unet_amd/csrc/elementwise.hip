@@ -405,16 +405,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdP p) {
   }
 }
 
-static int bn_bwd_ipb() {
-  static int v = 0;
-  if (!v) { const char* e = getenv("NUNET_BN_IPB"); v = e ? atoi(e) : 8; }
-  return v;
-}
-static int bn_bwd_cap(bool apply) {
-  static int cr = 0, ca = 0;
-  if (!cr) { const char* e = getenv("NUNET_BNR_CAP"); cr = e ? atoi(e) : 512; e = getenv("NUNET_BNA_CAP"); ca = e ? atoi(e) : 1024; }
-  return apply ? ca : cr;
-}
+// fat blocks: every block of the reduce pass ends with 2C fixed-point adds (8 pixels per thread, at most 512 / 1024 blocks)
+static int bn_bwd_ipb() { return 8; }
+static int bn_bwd_cap(bool apply) { return apply ? 1024 : 512; }
 template <typename T, bool APPLY> static int launch_bn_bwd_t(const nunet_bn_bwd_desc* d, hipStream_t st) {
   BnBwdP p;
   p.da = d->da; p.PDA = d->PDA; p.y = d->y; p.PY = d->PY; p.mi = d->mean_invstd; p.gamma = d->gamma; p.beta = d->beta;

@@ -584,8 +584,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   P->first_phase_nodes = unet ? 4 : 5;
   P->gs_bucket0 = 0;
   long long slab = 0;
-  int ks_max = 0;
-  { const char* e = getenv("NUNET_WG_KS_MAX"); ks_max = e ? atoi(e) : 0; }
+  const int ks_max = 0;
   for (int k = (int)P->exec.size() - 1; k >= 0; --k) {
     Node& n = P->exec[k];
     for (int cv = 1; cv >= 0; --cv) {
@@ -594,9 +593,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
       // K-split of the weight gradient: the two problems of a block share one launch, the one with fewer input
       // channels takes half the workgroups (fewer, fatter slices: less slab traffic)
       const ConvL& o = cv ? n.c1 : n.c2;
-      static int wt_small = 0, wt_big = 0;
-      if (!wt_small) { const char* e = getenv("NUNET_WG_TARGETS"); if (!e || sscanf(e, "%d,%d", &wt_small, &wt_big) != 2) { wt_small = 128; wt_big = 256; } }
-      c.wg_target = c.cinpad < o.cinpad ? wt_small : wt_big;
+      c.wg_target = c.cinpad < o.cinpad ? 128 : 256;     // (measured: 64/128, 64/256, 128/512, 256/512 are all slower in the step)
       nunet_wgrad_desc wd; memset(&wd, 0, sizeof(wd));
       wd.N = cfg->N; wd.H = P->hl[n.i]; wd.W = P->wl[n.i]; wd.C0 = c.cinpad; wd.Cout = c.cout; wd.target_wgs = c.wg_target; wd.max_slabs = ks_max;
       c.ks = nunet_conv3x3_wgrad_slabs(&wd);
@@ -922,16 +919,10 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
     if (capturing && (rt->cap_streams.empty())) multi = false;     // never warmed up eagerly: stay on one stream
     if (capturing && pass == 0) rt->cap_next = 0;                   // forward + backward of one capture share the pool
   }
-  {
-    // NUNET_LANE_MAP: 10 digits, lane of (level 0..4, wgrad of level 0..4). Default "0123401234":
-    // one lane per pyramid level, weight gradients on their level's lane (measured best on MI355X:
-    // separate wgrad lanes add cross-queue edges that cost more than the overlap they buy).
-    const char* e = getenv("NUNET_LANE_MAP");
-    for (int l = 0; l < NLANES; ++l) lane_map[l] = (e && strlen(e) == NLANES && e[l] >= '0' && e[l] <= '9') ? e[l] - '0' : l % 5;
-  }
-  static int lane_mod = 0;
-  if (!lane_mod) { const char* e = getenv("NUNET_LANE_MOD"); lane_mod = e ? atoi(e) : NLANES; if (lane_mod < 1 || lane_mod > NLANES) lane_mod = NLANES; }
-  for (int l = 0; l < NLANES; ++l) { lane_s[l] = capturing ? nullptr : rt->lanes[l % lane_mod]; used[l] = false; lane_tail[l] = nullptr; }
+  // lane of (level 0..4, weight gradients of level 0..4): one lane per pyramid level, weight gradients on their
+  // block's lane (measured best on MI355X: separate weight-gradient lanes add cross-queue edges that cost more than the
+  // overlap they buy; the exception is the deferral of the shallow chain blocks' weight gradients, see the backward pass)
+  for (int l = 0; l < NLANES; ++l) { lane_map[l] = l % 5; lane_s[l] = capturing ? nullptr : rt->lanes[l]; used[l] = false; lane_tail[l] = nullptr; }
   if (multi) {
     fork_ev = new_event();
     (void)hipEventRecord(fork_ev, main_s);
@@ -954,21 +945,14 @@ int Sched::run_ops() {
   return rc;
 }
 
-// Lane of a block. Crossing HW queues costs 5-10 us of dispatch latency per dependency edge, so the
-// assignment decides how many edges of the critical chain (B00>B10>B20>B30>B40>B31>B22>B13>B04 and its
-// mirror in backward) cross lanes. NUNET_LANE_MODE: 0 = pyramid level, 1 = anti-diagonal,
-// 2 = critical chain on lane 0 and the side blocks on lanes 1-3 by anti-diagonal.
+// Lane of a block. Crossing hardware queues costs 5-10 us of dispatch latency per dependency edge, so the assignment
+// decides how many edges of the critical chain (B00>B10>B20>B30>B40>B31>B22>B13>B04 and its mirror in backward) cross
+// lanes: the chain runs on lane 0, the side blocks on lanes 1-3 by anti-diagonal (measured best of seven assignments:
+// by level, by anti-diagonal, by column, one or two side lanes).
 static int lane_of(const nunet_plan* P, const Node& n) {
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("NUNET_LANE_MODE"); mode = e ? atoi(e) : 2; }   // measured best: 2
-  if (P->cfg.unet || mode == 0) return n.i;
-  if (mode == 1) return (n.i + n.j) % 5;
+  if (P->cfg.unet) return n.i;
   if (n.j == 0 || n.i + n.j == 4) return 0;
-  if (mode == 2) return n.i + n.j;           // side blocks: diagonals 1..3 -> lanes 1..3
-  if (mode == 3) return 1 + n.i;             // side blocks by level 0..2 -> lanes 1..3
-  if (mode == 4) return n.j;                 // side blocks by column 1..3 -> lanes 1..3
-  if (mode == 5) return 1 + (n.i + n.j) % 2; // two side lanes
-  return 1;                                  // mode 6: one side lane
+  return n.i + n.j;           // side blocks: diagonals 1..3 -> lanes 1..3
 }
 
 static int blk_index(const nunet_plan* P, int i, int in_prefix_zero_only) {
@@ -1359,8 +1343,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   Sched S; S.init(P, st, 1);
   int rc = NUNET_OK;
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
-  static int fuse_bnr = -1;
-  if (fuse_bnr < 0) { const char* e = getenv("NUNET_FUSE_BNR"); fuse_bnr = e ? atoi(e) : 1; }
+  const int fuse_bnr = 1;
   // reduce pass of block kt's second BatchNorm, for the kernel that completes its output gradient
   auto bnr_of = [&](int kt) {
     const Node& t = P->exec[kt];
@@ -1531,9 +1514,8 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       // The weight gradients of the shallow blocks of the critical chain (B04, B13, B22: full-chip launches) are held
       // back until the chain reaches the deep levels (B31 ..., grid-starved kernels that leave most CUs idle): they run
       // on lane 4 behind a dependency on the gradient that B22's upsample-backward hands to B31
-      static int defer = -1; if (defer < 0) { const char* e = getenv("NUNET_WG_DEFER"); defer = e ? atoi(e) : 1; }   // measured +1.9 %
-      int wl = wlane, r_gate = -1;
-      if (defer && !P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
+      int wl = wlane, r_gate = -1;     // (measured +1.9 % on the step)
+      if (!P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
       S.add(wl, 1, 0.f, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up, r_gate}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
             [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w1, &w2, ls); g_prof_alg_cin = 0; return r; });
     }

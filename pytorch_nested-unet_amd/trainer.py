@@ -252,9 +252,6 @@ class TrainStep:
         if not self.dp:
             # the whole step as ONE hipGraph (csrc/graph.hip), captured on a side stream, replayed on the caller's
             self.g_fb = _NativeGraph(s, lambda: (self._fwd_bwd(), self._opt()))
-            iters = int(os.environ.get("NUNET_GRAPH_TUNE", "0"))
-            if iters > 0:
-                self.tune_result = self.g_fb.tune(iters)
         else:
             if self.dp_auto:
                 self._choose_layout(s)
@@ -379,13 +376,6 @@ class _NativeGraph:
 
     def replay(self):
         L.check(L.lib().nunet_graph_launch(self.handle, L.stream()), "graph_launch")
-
-    def tune(self, iters, replays=6, seed=1):
-        import ctypes as C
-        base, best = C.c_float(), C.c_float()
-        torch.cuda.synchronize()
-        L.check(L.lib().nunet_graph_tune(self.handle, iters, replays, seed, C.byref(base), C.byref(best)), "graph_tune")
-        return base.value, best.value
 
     def __del__(self):
         try:

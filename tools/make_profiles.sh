@@ -1,18 +1,32 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): rocprofv3 passes behind profiles/rNN_*. Outputs under gpurun_out/prof_final/.
-# Each rocprofv3 invocation profiles `python3 bench.py` directly (no wrapper between -- and the program).
+# Run on the GPU box (gpurun -- tools/make_profiles.sh): every rocprofv3 pass behind profiles/rNN_*.
+# Outputs under gpurun_out/prof_final/; tools/summarize_profiles.py turns them into the tracked files.
+# Each rocprofv3 invocation profiles `python3 bench.py` directly (no wrapper between -- and the program); counter
+# passes carry only --kernel-trace beside --pmc.
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_final
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline"
+keep() {  # keep() <dir> <pattern> <dest>: copy the one csv we need, drop the rest
+  F=$(find $1 -name "$2" | head -1); cp "$F" "$3"; rm -rf $1
+}
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/multi -o run -- python3 $B > $O/multi.json 2> $O/multi.err
+keep $O/multi "*kernel_stats.csv" $O/multi_kernel_stats.csv
 echo "multi-lane done"
 NUNET_MULTISTREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/single -o run -- python3 $B > $O/single.json 2> $O/single.err
+keep $O/single "*kernel_stats.csv" $O/single_kernel_stats.csv
 echo "single-lane done"
-NUNET_MULTISTREAM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $B --no-graph > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-echo "pmc fetch done"
-NUNET_MULTISTREAM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $B --no-graph > $O/pmc_write.json 2> $O/pmc_write.err
-echo "pmc write done"
-ls $O/*
+# counter passes: eager (no hipGraph), single lane, 8 steps
+P="$R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-graph"
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" \
+         "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" \
+         "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
+  i=$((i+1))
+  NUNET_MULTISTREAM=0 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc$i -o run -- python3 $P > $O/pmc$i.json 2> $O/pmc$i.err
+  keep $O/pmc$i "*counter_collection.csv" $O/pmc$i.csv
+  echo "pmc pass $i done: $C"
+done
+ls -la $O
