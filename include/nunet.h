@@ -182,12 +182,10 @@ typedef struct {
 int nunet_bn_relu_bwd_reduce(const nunet_bn_bwd_desc* d, nunet_stream_t s);
 int nunet_bn_relu_bwd_apply(const nunet_bn_bwd_desc* d, nunet_stream_t s);
 
-/* BatchNorm+ReLU backward REDUCE fused into the kernel that COMPLETES a gradient tensor. The gradient of a block output
- * x_{i,j} is accumulated in its level-buffer slot by several kernels (dgrads of later blocks of the level, an
- * upsample-backward, a pool-backward, a head-backward); the LAST of them can take the reduce pass of that block's
- * second BatchNorm (sum dz, sum dz * xhat, as nunet_bn_relu_bwd_reduce) on the values it has just stored, which saves a
- * launch and a second read of the gradient. `*_bnr` entry points take this descriptor (NULL: plain kernel); C = the
- * channel count of the call. */
+/* BatchNorm+ReLU backward REDUCE fused into the kernel that COMPLETES a gradient tensor: nunet_head_bwd_bnr, the last
+ * writer of the output block's gradient, takes the reduce pass of that block's second BatchNorm (sum dz, sum dz * xhat,
+ * as nunet_bn_relu_bwd_reduce) on the values it has just stored - one launch less at the head of the backward chain.
+ * NULL descriptor: plain kernel. */
 typedef struct {
   const void* y; int32_t PY;        /* raw conv output the BatchNorm normalised, [pixels][PY] */
   const float* mean_invstd;         /* [2][C] saved by the BatchNorm forward */
@@ -205,18 +203,12 @@ int nunet_maxpool2x2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t
 int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
                          const void* x, int32_t PX, const void* dy, int32_t PDY,
                          void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s);
-int nunet_maxpool2x2_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
-                             const void* x, int32_t PX, const void* dy, int32_t PDY,
-                             void* dx, int32_t PDX, int32_t accumulate, const nunet_bnr_desc* bnr, nunet_stream_t s);
 /* H, W are the INPUT (low-res) extents; output is 2H x 2W */
 int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
                          const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s);
 int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
                          const void* dy, int32_t PDY, void* dx, int32_t PDX,
                          int32_t accumulate, nunet_stream_t s);
-int nunet_upsample2x_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
-                             const void* dy, int32_t PDY, void* dx, int32_t PDX,
-                             int32_t accumulate, const nunet_bnr_desc* bnr, nunet_stream_t s);
 
 /* ------------------------------------------------------------------------ */
 /* 1x1 heads: nn.Conv2d(32, num_classes, 1) at archs1.py:105-111,133-143     */

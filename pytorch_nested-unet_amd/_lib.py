@@ -120,10 +120,8 @@ _SIG = {
     "nunet_bn_relu_bwd_apply": (_i32, [C.POINTER(BnBwdDesc), _vp]),
     "nunet_maxpool2x2_fwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp]),
     "nunet_maxpool2x2_bwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp]),
-    "nunet_maxpool2x2_bwd_bnr": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(BnrDesc), _vp]),
     "nunet_upsample2x_fwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _vp]),
     "nunet_upsample2x_bwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _i32, _vp]),
-    "nunet_upsample2x_bwd_bnr": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _i32, _i32, C.POINTER(BnrDesc), _vp]),
     "nunet_head_fwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _vp]),
     "nunet_head_bwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "nunet_head_bwd_bnr": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, C.POINTER(BnrDesc), _vp]),

@@ -444,46 +444,71 @@ extern "C" int nunet_bn_relu_bwd_apply(const nunet_bn_bwd_desc* d, nunet_stream_
 }
 
 // ---------------------------------------------------------------------------
-// BatchNorm+ReLU backward REDUCE taken by the kernel that COMPLETES a gradient tensor (the last writer of a level-buffer
-// slot: an upsample-backward, a pool-backward or the head-backward), on the values it has just stored - instead of a
-// separate pass (nunet_bn_relu_bwd_reduce) that would read the gradient and the raw conv output again.
+// BatchNorm+ReLU backward REDUCE taken by the kernel that COMPLETES a gradient tensor, on the values it has just stored -
+// instead of a separate pass (nunet_bn_relu_bwd_reduce) that would read the gradient and the raw conv output again.
+// Used by the head backward (the last writer of x0_4's gradient, first kernel of the backward chain). The same fusion in
+// the upsample- and pool-backward kernels was measured and dropped: those run thousands of small latency-bound blocks,
+// and 2C fixed-point adds per block cost more (fused 21.9 us vs 9.4 + 8.6 us for the plain kernel + the fat-block reduce).
 // A thread's channel group is fixed (the launch geometry keeps grid stride % G == 0): coefficients and the two partial
 // sums of its EPV channels live in registers; the block reduces them in a fixed order, then one fixed-point add each.
 // ---------------------------------------------------------------------------
 struct BnrP { const void* y; int py; const float* mi; const float* gamma; const float* beta; long long* sums; int C; };
 template <typename T> struct BnrAcc {
   static constexpr int EPV = Tr<T>::EPV;
-  float mean[EPV], istd[EPV], sc[EPV], sh[EPV], r1[EPV], r2[EPV];
-  __device__ __forceinline__ void init(const BnrP& b, int cg) {
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      const int c = cg * EPV + e;
-      mean[e] = b.mi[c]; istd[e] = b.mi[b.C + c];
-      sc[e] = b.gamma[c] * istd[e]; sh[e] = __builtin_fmaf(-mean[e], sc[e], b.beta[c]);
-      r1[e] = 0.f; r2[e] = 0.f;
+  typedef typename FV<T>::type V;
+  V r1, r2;                                   // the only per-thread state: partial sums of this thread's EPV channels
+  // LDS: [sc | sh | istd | mean * istd][C] coefficient table (a thread visits one or two elements: per-thread coefficient
+  // registers would cost 32 VGPRs and halve the occupancy of a gather kernel that lives on it), then the reduction scratch
+  static constexpr int LDS_FLOATS(int) { return 0; }
+  __device__ __forceinline__ void init(const BnrP& b, float* s_tab) {
+    for (int c = threadIdx.x; c < b.C; c += blockDim.x) {
+      const float mean = b.mi[c], istd = b.mi[b.C + c];
+      const float sc = b.gamma[c] * istd;
+      s_tab[c] = sc; s_tab[b.C + c] = __builtin_fmaf(-mean, sc, b.beta[c]); s_tab[2 * b.C + c] = istd; s_tab[3 * b.C + c] = mean * istd;
     }
-  }
-  // `stored`: the gradient vector as written (rounded to T); pix: its pixel index in the BN's tensor
-  __device__ __forceinline__ void add(const BnrP& b, int cg, long long pix, const Vec16<T>& stored) {
-    const Vec16<T> yv = ld16((const T*)b.y + pix * b.py + cg * EPV);
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-      const float yy = yv.get(e);
-      const float dz = __builtin_fmaf(yy, sc[e], sh[e]) > 0.f ? stored.get(e) : 0.f;
-      r1[e] += dz; r2[e] += dz * ((yy - mean[e]) * istd[e]);
-    }
-  }
-  // s_part: 256 * 2 * EPV floats of LDS; G = channel groups; all 256 threads of the block call this
-  __device__ __forceinline__ void finish(const BnrP& b, float* s_part, int G) {
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) { s_part[(threadIdx.x * 2 + 0) * EPV + e] = r1[e]; s_part[(threadIdx.x * 2 + 1) * EPV + e] = r2[e]; }
+    r1 = V(0.f); r2 = V(0.f);
     __syncthreads();
-    const int ppb = blockDim.x / G;
+  }
+  __device__ __forceinline__ Vec16<T> fetch(const BnrP& b, int cg, long long pix) const { return ld16((const T*)b.y + pix * b.py + cg * EPV); }
+  // `stored`: the gradient vector as written (rounded to T); yv: the raw conv output at the same pixel (fetch(), issued early)
+  __device__ __forceinline__ void add(const BnrP& b, const float* s_tab, int cg, const Vec16<T>& yv, const Vec16<T>& stored) {
+    const V y = vec_to_f<T>(yv), g = vec_to_f<T>(stored);
+    const V sc = ldf<T>(&s_tab[cg * EPV]), sh = ldf<T>(&s_tab[b.C + cg * EPV]);
+    const V istd = ldf<T>(&s_tab[2 * b.C + cg * EPV]), mis = ldf<T>(&s_tab[3 * b.C + cg * EPV]);
+    const V act = __builtin_elementwise_fma(y, sc, sh);
+    const V dz = act > V(0.f) ? g : V(0.f);
+    r1 += dz;
+    r2 += dz * __builtin_elementwise_fma(y, istd, -mis);      // dz * xhat
+  }
+  // Block reduction in a fixed order, then ONE fixed-point add per channel and sum: lanes of a wave that share a channel
+  // group (lane % G when G < 64) are summed with xor-shuffles, the waves meet in LDS (s_part: waves x 2 x C floats).
+  // Blocks of 1024 threads keep the number of adds per launch low: every block ends with 2C same-address atomics, and
+  // a thousand small blocks hammering 64 cache lines cost more than the kernel itself.
+  __device__ __forceinline__ void finish(const BnrP& b, float* s_part, int G) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (G < 64) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        if (off >= G) {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) { r1[e] += __shfl_xor(r1[e], off); r2[e] += __shfl_xor(r2[e], off); }
+        }
+      }
+    }
+    // after the shuffles lanes 0..min(G,64)-1 hold the wave's sums of channel groups (threadIdx.x % G)
+    const int gl = G < 64 ? G : 64;
+    if (lane < gl) {
+      const int g = threadIdx.x % G;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { s_part[(wv * 2 + 0) * b.C + g * EPV + e] = r1[e]; s_part[(wv * 2 + 1) * b.C + g * EPV + e] = r2[e]; }
+    }
+    __syncthreads();
+    // waves that own channel group g: all of them when G <= 64, else waves wv with (wv * 64) % G == g - (g % 64)
     for (int t = threadIdx.x; t < 2 * b.C; t += blockDim.x) {
       const int v = t / b.C, c = t - v * b.C;
-      const int g = c / EPV, e = c - g * EPV;
       float sum = 0.f;
-      for (int q = 0; q < ppb; ++q) sum += s_part[((q * G + g) * 2 + v) * EPV + e];
+      if (G <= 64) { for (int q = 0; q < nw; ++q) sum += s_part[(q * 2 + v) * b.C + c]; }
+      else { const int g = c / EPV, per = G / 64; for (int q = (g / 64); q < nw; q += per) sum += s_part[(q * 2 + v) * b.C + c]; }
       fx_add(b.sums + ((size_t)((blockIdx.x & (bn_sum_replicas(b.C) - 1)) * 2 + v) * b.C + c) * NUNET_FX_WORDS, sum);
     }
   }
@@ -520,14 +545,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     st16(y + q * PY + cg * EPV, o);
   }
 }
-template <typename T, bool BNR>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int PX, const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc, BnrP bn) {
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int PX, const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc) {
   constexpr int EPV = Tr<T>::EPV;
   const int G = C / EPV, H2 = H / 2, W2 = W / 2;
   const int64_t total = (int64_t)N * H2 * W2 * G;
-  __shared__ float s_part[BNR ? 256 * 2 * EPV : 1];
-  BnrAcc<T> ba;
-  if constexpr (BNR) ba.init(bn, threadIdx.x % G);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int cg, qx, qy, n; long long q;
     dec4(dc, i, cg, q, qx, qy, n);
@@ -558,10 +580,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         o.set(e, am[e] == k ? base + g.get(e) : base);
       }
       st16(q4, o);
-      if constexpr (BNR) ba.add(bn, cg, p00 + (k >> 1) * W + (k & 1), o);
     }
   }
-  if constexpr (BNR) ba.finish(bn, s_part, G);
 }
 template <typename T> static int launch_maxpool_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
@@ -569,22 +589,10 @@ template <typename T> static int launch_maxpool_fwd(int N, int H, int W, int C, 
   NUNET_LAUNCH((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
   return nunet_check_launch("maxpool_fwd");
 }
-// (block size 256 and a grid stride that is a multiple of the channel groups keep a thread's channel group fixed)
-static int bnr_grid(int64_t total, int per_block, int G, int cap) {
-  int g = grid_for(total, per_block, cap);
-  (void)G;            // 256 % G == 0 is checked by the callers, so any grid keeps (grid * 256) % G == 0
-  return g;
-}
-template <typename T> static int launch_maxpool_bwd(int N, int H, int W, int C, const void* x, int PX, const void* dy, int PDY, void* dx, int PDX, int acc, const nunet_bnr_desc* bnr, hipStream_t st) {
+template <typename T> static int launch_maxpool_bwd(int N, int H, int W, int C, const void* x, int PX, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / Tr<T>::EPV);
-  ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * ((acc ? 3.25 : 2.25) + (bnr ? 1.0 : 0.0)), st);
-  BnrP b; memset(&b, 0, sizeof(b));
-  if (bnr) {
-    NUNET_REQUIRE(256 % (C / Tr<T>::EPV) == 0, "maxpool_bwd: fused BN reduce needs C / %d to divide 256", Tr<T>::EPV);
-    int rc = bnr_fill(b, bnr, C, Tr<T>::DT); if (rc) return rc;
-    NUNET_LAUNCH((maxpool_bwd_kernel<T, true>), dim3(grid_for(total, 256 * 2, 1024)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2), b);
-  } else
-    NUNET_LAUNCH((maxpool_bwd_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2), b);
+  ProfScope ps(PC_POOL, 0, (double)N * H * W * C * sizeof(T) * (acc ? 3.25 : 2.25), st);
+  NUNET_LAUNCH((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W / 2, H / 2));
   return nunet_check_launch("maxpool_bwd");
 }
 static int ew_check(const char* what, int dtype, int N, int H, int W, int C, int p0, int p1) {
@@ -599,14 +607,11 @@ extern "C" int nunet_maxpool2x2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t
   NUNET_REQUIRE(x && y && H % 2 == 0 && W % 2 == 0, "maxpool_fwd: needs even H, W");
   return NUNET_DISPATCH(dtype, launch_maxpool_fwd, N, H, W, C, x, PX, y, PY, (hipStream_t)s);
 }
-extern "C" int nunet_maxpool2x2_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, const nunet_bnr_desc* bnr, nunet_stream_t s) {
+extern "C" int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
   int rc = ew_check("maxpool_bwd", dtype, N, H, W, C, PX, PDX);
   if (rc) return rc;
   NUNET_REQUIRE(x && dy && dx && H % 2 == 0 && W % 2 == 0 && PDY % (16 / dtype_size(dtype)) == 0, "maxpool_bwd: bad args");
-  return NUNET_DISPATCH(dtype, launch_maxpool_bwd, N, H, W, C, x, PX, dy, PDY, dx, PDX, accumulate, bnr, (hipStream_t)s);
-}
-extern "C" int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
-  return nunet_maxpool2x2_bwd_bnr(dtype, N, H, W, C, x, PX, dy, PDY, dx, PDX, accumulate, nullptr, s);
+  return NUNET_DISPATCH(dtype, launch_maxpool_bwd, N, H, W, C, x, PX, dy, PDY, dx, PDX, accumulate, (hipStream_t)s);
 }
 
 // ---------------------------------------------------------------------------
@@ -644,13 +649,10 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
   }
 }
 // gather form of the transposed interpolation: one thread per low-res pixel
-template <typename T, bool BNR>
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc, BnrP bn) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, int PDY, T* __restrict__ dx, int PDX, int accumulate, int N, int H, int W, int C, Dec4 dc) {
   constexpr int EPV = Tr<T>::EPV;
   const int G = C / EPV, HO = 2 * H, WO = 2 * W;
-  __shared__ float s_part[BNR ? 256 * 2 * EPV : 1];
-  BnrAcc<T> ba;
-  if constexpr (BNR) ba.init(bn, threadIdx.x % G);
   const float sy = HO > 1 ? (float)(H - 1) / (float)(HO - 1) : 0.f;
   const float sx = WO > 1 ? (float)(W - 1) / (float)(WO - 1) : 0.f;
   const int64_t total = (int64_t)N * H * W * G;
@@ -722,9 +724,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < EPV; ++e) r.set(e, (accumulate ? r.get(e) : 0.f) + acc[e]);
     st16(q, r);
-    if constexpr (BNR) ba.add(bn, cg, o, r);
   }
-  if constexpr (BNR) ba.finish(bn, s_part, G);
 }
 template <typename T> static int launch_up_fwd(int N, int H, int W, int C, const void* x, int PX, void* y, int PY, hipStream_t st) {
   const int64_t total = (int64_t)N * 4 * H * W * (C / Tr<T>::EPV);
@@ -732,17 +732,10 @@ template <typename T> static int launch_up_fwd(int N, int H, int W, int C, const
   NUNET_LAUNCH((upsample_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, PX, (T*)y, PY, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, 2 * W, 2 * H));
   return nunet_check_launch("upsample_fwd");
 }
-template <typename T> static int launch_up_bwd(int N, int H, int W, int C, const void* dy, int PDY, void* dx, int PDX, int acc, const nunet_bnr_desc* bnr, hipStream_t st) {
+template <typename T> static int launch_up_bwd(int N, int H, int W, int C, const void* dy, int PDY, void* dx, int PDX, int acc, hipStream_t st) {
   const int64_t total = (int64_t)N * H * W * (C / Tr<T>::EPV);
-  ProfScope ps(PC_UP_BWD, 0, (double)N * H * W * C * sizeof(T) * ((acc ? 6.0 : 5.0) + (bnr ? 1.0 : 0.0)), st);
-  BnrP b; memset(&b, 0, sizeof(b));
-  if (bnr) {
-    NUNET_REQUIRE(256 % (C / Tr<T>::EPV) == 0, "upsample_bwd: fused BN reduce needs C / %d to divide 256", Tr<T>::EPV);
-    int rc = bnr_fill(b, bnr, C, Tr<T>::DT); if (rc) return rc;
-    // (fewer, fatter blocks: every block ends with 2C fixed-point adds)
-    NUNET_LAUNCH((upsample_bwd_kernel<T, true>), dim3(grid_for(total, 256 * 2, 1024)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H), b);
-  } else
-    NUNET_LAUNCH((upsample_bwd_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H), b);
+  ProfScope ps(PC_UP_BWD, 0, (double)N * H * W * C * sizeof(T) * (acc ? 6.0 : 5.0), st);
+  NUNET_LAUNCH((upsample_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, PDY, (T*)dx, PDX, acc, N, H, W, C, make_dec4(total, C / Tr<T>::EPV, W, H));
   return nunet_check_launch("upsample_bwd");
 }
 extern "C" int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int32_t PX, void* y, int32_t PY, nunet_stream_t s) {
@@ -751,14 +744,11 @@ extern "C" int nunet_upsample2x_fwd(int32_t dtype, int32_t N, int32_t H, int32_t
   NUNET_REQUIRE(x && y, "upsample_fwd: null pointer");
   return NUNET_DISPATCH(dtype, launch_up_fwd, N, H, W, C, x, PX, y, PY, (hipStream_t)s);
 }
-extern "C" int nunet_upsample2x_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, const nunet_bnr_desc* bnr, nunet_stream_t s) {
+extern "C" int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
   int rc = ew_check("upsample_bwd", dtype, N, H, W, C, PDY, PDX);
   if (rc) return rc;
   NUNET_REQUIRE(dy && dx, "upsample_bwd: null pointer");
-  return NUNET_DISPATCH(dtype, launch_up_bwd, N, H, W, C, dy, PDY, dx, PDX, accumulate, bnr, (hipStream_t)s);
-}
-extern "C" int nunet_upsample2x_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy, int32_t PDY, void* dx, int32_t PDX, int32_t accumulate, nunet_stream_t s) {
-  return nunet_upsample2x_bwd_bnr(dtype, N, H, W, C, dy, PDY, dx, PDX, accumulate, nullptr, s);
+  return NUNET_DISPATCH(dtype, launch_up_bwd, N, H, W, C, dy, PDY, dx, PDX, accumulate, (hipStream_t)s);
 }
 
 // ---------------------------------------------------------------------------
@@ -804,9 +794,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   constexpr int KM = KT > 0 ? KT : HEAD_MAXK;
   __shared__ float s_dw[4 * (HEAD_MAXK * 32 + HEAD_MAXK)];   // per wave
   const int cg = threadIdx.x % G, pl = threadIdx.x / G, ppb = blockDim.x / G;
-  __shared__ float s_part[BNR ? 256 * 2 * EPV : 1];
+  __shared__ __attribute__((aligned(16))) float s_part[BNR ? 4096 : 1];   // waves x 2 x C floats (BnrAcc::finish)
+  __shared__ __attribute__((aligned(16))) float s_tab[BNR ? 4 * 32 : 1];
   BnrAcc<T> ba;
-  if constexpr (BNR) ba.init(bn, cg);
+  if constexpr (BNR) ba.init(bn, s_tab);
   float wk[KM][EPV], aw[KM][EPV], ab[KM];
 #pragma unroll
   for (int k = 0; k < KM; ++k) {
@@ -821,7 +812,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   constexpr int U = 4;
   const int64_t stride = (int64_t)gridDim.x * ppb;
   for (int64_t pix0 = (int64_t)blockIdx.x * ppb + pl; pix0 < npix; pix0 += U * stride) {
-    Vec16<T> xv[U], ov[U];
+    Vec16<T> xv[U], ov[U], yb[BNR ? U : 1];
     float d[U][KM];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -831,6 +822,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         const int rem = (int)pix - n * hw;
         xv[u] = ld16(x + pix * PX + cg * EPV);
         if (dx && accumulate) ov[u] = ld16(dx + pix * PDX + cg * EPV);
+        if constexpr (BNR) yb[u] = ba.fetch(bn, cg, pix);
 #pragma unroll
         for (int k = 0; k < KM; ++k) d[u][k] = (KT > 0 || k < K) ? dl[((int64_t)n * K + k) * hw + rem] : 0.f;
       }
@@ -855,7 +847,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
 #pragma unroll
           for (int e = 0; e < EPV; ++e) o.set(e, (accumulate ? ov[u].get(e) : 0.f) + g[e]);
           st16(dx + pix * PDX + cg * EPV, o);
-          if constexpr (BNR) ba.add(bn, cg, pix, o);
+          if constexpr (BNR) ba.add(bn, s_tab, cg, yb[u], o);
         }
       }
     }

@@ -1301,9 +1301,9 @@ static int launch_reduce(nunet_plan* P, void* arena, int k_lo, int k_hi, hipStre
 // of a block of level l whose concat holds slot s, the upsample-backward of the level l-1 block that upsampled it, the
 // pool-backward of the level l+1 encoder block (slot 0). Ops are issued heads first, then blocks for k descending, and
 // writers of one slot are serialised in that order by the lane scheduler - so the last writer is the block writer with
-// the smallest k (or the head when no block writes the slot). It takes the BatchNorm-backward reduce of x_{l,s}'s block
-// in its epilogue when it is a head / upsample-backward / pool-backward (nunet_*_bwd_bnr); conv dgrads (three level-0
-// blocks of the nested net) leave it to the stand-alone reduce.
+// the smallest k (or the head when no block writes the slot). A head that completes its slot (the output block's) takes
+// that block's BatchNorm-backward reduce in its epilogue (nunet_head_bwd_bnr); every other block runs the stand-alone
+// reduce (the same fusion in upsample- / pool-backward was measured slower, see elementwise.hip).
 enum { LW_NONE = 0, LW_HEAD, LW_DGRAD, LW_UPB, LW_POOLB };
 static void last_writer(const nunet_plan* P, int l, int s, int& kind, int& kk) {
   kind = LW_NONE; kk = 1 << 30;
@@ -1343,7 +1343,6 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   Sched S; S.init(P, st, 1);
   int rc = NUNET_OK;
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
-  const int fuse_bnr = 1;
   // reduce pass of block kt's second BatchNorm, for the kernel that completes its output gradient
   auto bnr_of = [&](int kt) {
     const Node& t = P->exec[kt];
@@ -1353,7 +1352,6 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     return b;
   };
   auto completes = [&](int l, int sl, int kind, int k) {      // does op (kind, block k) complete x_{l,sl}'s gradient?
-    if (!fuse_bnr) return -1;
     int lk, lkk; last_writer(P, l, sl, lk, lkk);
     if (lk != kind || (kind != LW_HEAD && lkk != k)) return -1;
     return block_of_slot(P, l, sl);
@@ -1408,7 +1406,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     b2.sums = (int64_t*)fx_of(arena, P, 1, L2.bsum);
     {
       int lk, lkk; last_writer(P, i, n.out_slot, lk, lkk);
-      const bool fused = fuse_bnr && (lk == LW_HEAD || lk == LW_UPB || lk == LW_POOLB);   // taken by the op that completed the gradient
+      const bool fused = lk == LW_HEAD;   // taken by the head backward, which completed the gradient
       if (!fused) {
         S.name("B%d%d.bnR2", n.i, n.j);
         S.add(lane, 0, 0.f, {r_gxo, rb + B_Y2}, {r_v2}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_reduce(&b2, ls); });
@@ -1451,13 +1449,10 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
         S.add(lane, 0, 0.f, {r_da1, rb + B_Y1, r_v1, R_WP + i}, {r_dy1, rl + L_GPIN, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
         // through MaxPool2d(2,2) into x_{i-1,0}
         const int acc = written[i - 1][0] ? 1 : 0;
-        const int kt = completes(i - 1, 0, LW_POOLB, k);
-        nunet_bnr_desc bd; memset(&bd, 0, sizeof(bd));
-        if (kt >= 0) bd = bnr_of(kt);
         S.name("B%d%d.poolB", n.i, n.j);
-        S.add(lane, 0, 0.f, {rl + L_GPIN, R_X + (i - 1) * 5 + 0, kt >= 0 ? R_BLK + kt * B_STRIDE + B_Y2 : -1}, {R_GX + (i - 1) * 5 + 0, kt >= 0 ? R_GSV + 2 * kt + 1 : -1}, [=](hipStream_t ls) {
-          return nunet_maxpool2x2_bwd_bnr(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
-                                          AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], acc, kt >= 0 ? &bd : nullptr, ls);
+        S.add(lane, 0, 0.f, {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0}, [=](hipStream_t ls) {
+          return nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
+                                      AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], acc, ls);
         });
         written[i - 1][0] = true;
       } else {
@@ -1469,13 +1464,10 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
                n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
         // through the bilinear upsample into x_{i+1,up_slot}
         const int acc = written[i + 1][n.up_slot] ? 1 : 0;
-        const int kt = completes(i + 1, n.up_slot, LW_UPB, k);
-        nunet_bnr_desc bd; memset(&bd, 0, sizeof(bd));
-        if (kt >= 0) bd = bnr_of(kt);
         S.name("B%d%d.upB", n.i, n.j);
-        S.add(lane, 0, 0.f, {rl + L_GUP, kt >= 0 ? R_BLK + kt * B_STRIDE + B_Y2 : -1}, {R_GX + (i + 1) * 5 + n.up_slot, kt >= 0 ? R_GSV + 2 * kt + 1 : -1}, [=](hipStream_t ls) {
-          return nunet_upsample2x_bwd_bnr(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
-                                          AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], acc, kt >= 0 ? &bd : nullptr, ls);
+        S.add(lane, 0, 0.f, {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot}, [=](hipStream_t ls) {
+          return nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
+                                      AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], acc, ls);
         });
         written[i + 1][n.up_slot] = true;
       }

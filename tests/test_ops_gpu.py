@@ -459,32 +459,11 @@ def _bnr_check(dt, n, h, w, c, da_ptr, pda, sums, keep):
 
 @pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
 @pytest.mark.parametrize("acc", [0, 1])
-def test_fused_bn_reduce_in_upsample_pool_head_bwd(dt, acc):
-    """nunet_upsample2x_bwd_bnr / nunet_maxpool2x2_bwd_bnr / nunet_head_bwd_bnr: same gradients as the plain kernels,
-    plus the BatchNorm-backward sums of the tensor they complete."""
+def test_fused_bn_reduce_in_head_bwd(dt, acc):
+    """nunet_head_bwd_bnr: same gradients as the plain kernel, plus the BatchNorm-backward sums of the tensor it completes."""
     g = torch.Generator().manual_seed(41 + acc)
-    # upsample backward: low-res gradient [n, c, h, w] in a slot of a wider buffer
-    n, c, h, w = 3, 64, 12, 10
-    dy = nhwc(q(torch.randn(n, c, 2 * h, 2 * w, generator=g), dt), dt)
-    prev = q(torch.randn(n, c, h, w, generator=g), dt)
+    n, h, w = 3, 12, 10
     es = 4 if dt == L.F32 else 2
-    d, sums, keep = _bnr_setup(n, h, w, c, dt, g)
-    a = nhwc(prev, dt, pitch=192, off=64); b_ = nhwc(prev, dt, pitch=192, off=64)
-    L.check(L.lib().nunet_upsample2x_bwd(dt, n, h, w, c, L.ptr(dy), c, L.ptr(a, 64 * es), 192, acc, L.stream()), "up")
-    L.check(L.lib().nunet_upsample2x_bwd_bnr(dt, n, h, w, c, L.ptr(dy), c, L.ptr(b_, 64 * es), 192, acc, C.byref(d), L.stream()), "up bnr")
-    assert torch.equal(a, b_)
-    _bnr_check(dt, n, h, w, c, L.ptr(b_, 64 * es), 192, sums, keep)
-    # pool backward: high-res gradient [n, c, 2h, 2w]
-    x = nhwc(q(torch.randn(n, c, 2 * h, 2 * w, generator=g), dt), dt)
-    dyp = nhwc(q(torch.randn(n, c, h, w, generator=g), dt), dt)
-    prevh = q(torch.randn(n, c, 2 * h, 2 * w, generator=g), dt)
-    d, sums, keep = _bnr_setup(n, 2 * h, 2 * w, c, dt, g)
-    a, b_ = nhwc(prevh, dt), nhwc(prevh, dt)
-    L.check(L.lib().nunet_maxpool2x2_bwd(dt, n, 2 * h, 2 * w, c, L.ptr(x), c, L.ptr(dyp), c, L.ptr(a), c, acc, L.stream()), "pool")
-    L.check(L.lib().nunet_maxpool2x2_bwd_bnr(dt, n, 2 * h, 2 * w, c, L.ptr(x), c, L.ptr(dyp), c, L.ptr(b_), c, acc, C.byref(d), L.stream()), "pool bnr")
-    assert torch.equal(a, b_)
-    _bnr_check(dt, n, 2 * h, 2 * w, c, L.ptr(b_), c, sums, keep)
-    # head backward: 32 channels, slot of the level-0 buffer
     k, c = 2, 32
     xh = nhwc(q(torch.randn(n, c, h, w, generator=g), dt), dt, pitch=160, off=128)
     wt = (torch.randn(k, c, generator=g) * 0.2).to(DEV)
