@@ -116,6 +116,7 @@ struct ConvP {
   int SH;                // stacked-rows tiling: H + 1 (0 = off), see map_pixel
   unsigned SHinv;        // ceil(2^32 / SH)
   unsigned invS, invCoT, invTX, invTY;   // fastdiv_inv of S, nCoT, tilesX, tilesY (item decode)
+  unsigned invTHW, invTW, invHH2HW2, invHW2;   // ... of TH*TW, TW, (TH+2)*(TW+2), TW+2 (tile-invariant tables of the prologue)
   int S, nch0, nch;      // K-split: slices, channel chunks of source 0 / total (SK kernels only)
   float* slabs;          // [S][pixels][Cout] fp32 partial sums
   long long slab_stride; // pixels * Cout
@@ -160,6 +161,19 @@ template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
 };
 
 // floats of dynamic LDS a launch needs for its per-channel coefficient tables
+// Diagnostic build only (-DNUNET_KSTAMP, tools/kstamp_build.sh): wave 0 of the first workgroups writes s_memtime
+// at the phase boundaries of its first items, so a per-phase cycle budget of the persistent loop can be read back.
+#ifdef NUNET_KSTAMP
+__device__ unsigned long long* g_kstamp; __device__ int g_kstamp_wgs;
+extern "C" int nunet_kstamp_set(void* buf, int wgs) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_kstamp), &buf, sizeof(buf)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_kstamp_wgs), &wgs, sizeof(wgs)) != hipSuccess;
+}
+#define KSTAMP(i) do { if (threadIdx.x == 0 && (int)blockIdx.x < g_kstamp_wgs && (i) < 32) g_kstamp[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KSTAMP(i) do {} while (0)
+#endif
+
 static inline int conv_coef_floats(int lt, int cin, bool bnr, int cout) { return (lt == 1 ? 2 : lt == 2 ? 4 : 0) * cin + (bnr ? 4 * cout : 0); }
 
 // Persistent kernel: each workgroup walks (tile, Cout-tile) items with stride gridDim.x.
@@ -193,11 +207,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   const int HW2 = p.TW + 2, HH2 = p.TH + 2;
   const int HP = p.NI * HH2 * HW2;
   const int THW = p.TH * p.TW;
+  KSTAMP(0);
+  [[maybe_unused]] int kst = 4;   // NUNET_KSTAMP: next stamp slot of the loop
 
+  // (divisions by launch constants as multiplies by host-computed inverses: the generic 32-bit division is ~30 instructions,
+  //  and this prologue is a quarter of a workgroup's lifetime on the one-chunk layers of the first level)
   for (int m = tid; m < BM; m += NT) {
-    const int ni = m / THW;
+    const int ni = fastdiv(m, p.invTHW);
     const int rem = m - ni * THW;
-    const int ly = rem / p.TW, lx = rem - ly * p.TW;
+    const int ly = fastdiv(rem, p.invTW), lx = rem - ly * p.TW;
     const bool ok = ni < p.NI;
     s_hidx[m] = ok ? ((ni * HH2 + ly + 1) * HW2 + lx + 1) : (HW2 + 1);
     s_mxy[m] = ok ? ((ni << 20) | (ly << 10) | lx) : -1;
@@ -205,14 +223,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   for (int hp = tid; hp < C::HPMAX; hp += NT) {
     int code = -1;
     if (hp < HP) {
-      const int ni = hp / (HH2 * HW2);
+      const int ni = fastdiv(hp, p.invHH2HW2);
       const int rem = hp - ni * (HH2 * HW2);
-      const int hy = rem / HW2, hx = rem - hy * HW2;
+      const int hy = fastdiv(rem, p.invHW2), hx = rem - hy * HW2;
       code = (ni << 20) | (hy << 10) | hx;
     }
     s_hxy[hp] = code;
   }
   __syncthreads();
+  KSTAMP(1);
 
   int abase[SM];
 #pragma unroll
@@ -269,17 +288,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   // pixel * pitch + its 16-byte segment + the chunk's (uniform) channel offset - two VALU per unit and chunk and no
   // 64-bit pointer per unit held across the MFMA sweep. A pixel outside the image reads pixel 0 and is zeroed on the
   // way to LDS (write_lds), so a chunk's staging stays 12 plain 16-byte loads without branches.
-  unsigned woff[C::UW];
-  auto set_ptrs = [&](const Item& it) {
+  unsigned woff[C::UW];              // tile-invariant: weight row (tap, co within the Cout tile) + segment
 #pragma unroll
-    for (int k = 0; k < C::UW; ++k) {
-      const int u = tid + k * NT;
-      const int row = u >> 2;
-      const int tap = row / BN, co = row - tap * BN;
-      // (a unit past the last weight row exists when 9*BN*4 is not a multiple of NT; it re-reads row 0 and is never written to LDS)
-      woff[k] = row < 9 * BN ? (unsigned)(((tap * p.Cout + it.co0 + co) * p.Cin + seg * EPV) * (int)sizeof(T)) : (unsigned)(seg * 16);
-    }
-  };
+  for (int k = 0; k < C::UW; ++k) {
+    const int u = tid + k * NT;
+    const int row = u >> 2;
+    const int tap = row / BN, co = row - tap * BN;
+    // (a unit past the last weight row exists when 9*BN*4 is not a multiple of NT; it re-reads row 0 and is never written to LDS)
+    woff[k] = row < 9 * BN ? (unsigned)(((tap * p.Cout + co) * p.Cin + seg * EPV) * (int)sizeof(T)) : (unsigned)(seg * 16);
+  }
+  unsigned wco = 0u;                 // the loaded item's Cout tile: co0 * Cin elements, in bytes (uniform)
+  auto set_ptrs = [&](const Item& it) { wco = (unsigned)(it.co0 * p.Cin * (int)sizeof(T)); };
   auto load_regs = [&](int kb) {
     const bool s0 = LT != 0 || kb < p.C0;
     const char* const base = (const char*)(s0 ? p.src0 : p.src1);
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       hreg[k].raw = *reinterpret_cast<const u32x4*>(base + (gp * pb + cb));
       if constexpr (LT == 2) yreg[k].raw = *reinterpret_cast<const u32x4*>((const char*)p.tf_y + (gp * ((unsigned)p.tf_py * (unsigned)sizeof(T)) + (unsigned)(kb * (int)sizeof(T) + seg * 16)));
     }
-    const unsigned wb = (unsigned)(kb * (int)sizeof(T));
+    const unsigned wb = (unsigned)(kb * (int)sizeof(T)) + wco;
 #pragma unroll
     for (int k = 0; k < C::UW; ++k) wreg[k].raw = *reinterpret_cast<const u32x4*>((const char*)p.w + (woff[k] + wb));
   };
@@ -385,26 +404,43 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       }
     }
   };
+  float biasr[SN];                   // bias of this thread's output channels for the item being computed (set with s_gpix)
+#pragma unroll
+  for (int b = 0; b < SN; ++b) biasr[b] = 0.f;
+  static_assert(SM * 16 <= 32, "row-validity mask of the epilogue is one 32-bit word");
   auto epi_plain = [&](const Item& cur, T* const s_out) {
     // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
+    // Nothing in here waits on a global LOAD unless a destination accumulates: the bias was fetched when the item
+    // started, and a wait would also drain the next item's staging loads already in flight (the counter is in-order).
+    constexpr int SEGS = BN / EPV;
+    const int sg = tid % SEGS, m0 = tid / SEGS;       // NT % SEGS == 0: every store unit of a thread has the same channel segment
     // BNR: the y1 vectors of this thread's store units are requested NOW, so their latency hides under
     // the accumulator -> LDS transposition below instead of being exposed once per unit in the store loop
     Vec16<T> byv[BNR ? C::UO : 1];
-    if constexpr (BNR) {
-      constexpr int SEGS0 = BN / EPV;
+    int gpu[C::UO];
 #pragma unroll
-      for (int k = 0; k < C::UO; ++k) {
-        const int u = tid + k * NT;
-        const int m = u / SEGS0, sg = u - m * SEGS0;
-        const int gp = m < BM ? s_gpix[m] : -1;
-        if (gp >= 0) byv[k] = ld16((const T*)p.bn_y + (size_t)gp * p.bn_py + cur.co0 + sg * EPV);
-      }
+    for (int k = 0; k < C::UO; ++k) {
+      const int m = m0 + k * (NT / SEGS);
+      gpu[k] = m < BM ? s_gpix[m] : -1;
+    }
+    if constexpr (BNR) {
+#pragma unroll
+      for (int k = 0; k < C::UO; ++k)
+        if (gpu[k] >= 0) byv[k] = ld16((const T*)p.bn_y + (size_t)gpu[k] * p.bn_py + cur.co0 + sg * EPV);
+    }
+    // which of this thread's accumulator rows are pixels of the image (all 16*SM reads in flight at once)
+    unsigned rowmask = 0u;
+    if (p.stats) {
+#pragma unroll
+      for (int a = 0; a < SM; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rowmask |= (s_gpix[(wm * SM + a) * 32 + acc_row(i, h)] >= 0 ? 1u : 0u) << (a * 16 + i);
     }
     __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
 #pragma unroll
     for (int b = 0; b < SN; ++b) {
       const int cl = (wn * SN + b) * 32 + r;  // channel within the tile
-      const float bias = p.bias ? p.bias[cur.co0 + cl] : 0.f;
+      const float bias = biasr[b];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int a = 0; a < SM; ++a) {
@@ -413,10 +449,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
           const int m = (wm * SM + a) * 32 + acc_row(i, h);
           const T tv = from_f32<T>(acc[a][b][i] + bias);
           s_out[m * OS + cl] = tv;
-          if (p.stats && s_gpix[m] >= 0) {
-            const float d = to_f32(tv) - bias;
-            s1 += d; s2 += d * d;
-          }
+          const float d = ((rowmask >> (a * 16 + i)) & 1u) ? to_f32(tv) - bias : 0.f;
+          s1 += d; s2 += d * d;
           acc[a][b][i] = 0.f;
         }
       }
@@ -427,50 +461,48 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       }
     }
     __syncthreads();
-    constexpr int SEGS = BN / EPV;
-    // BNR: every unit of a thread has the same channel segment (NT % SEGS == 0), so the BN-backward
-    // partial sums of its 8 channels live in registers across the store loop
+    // BNR: the BN-backward partial sums of the thread's 8 channels live in registers across the store loop
     float bmean[BNR ? EPV : 1], bistd[BNR ? EPV : 1], bsc[BNR ? EPV : 1], bsh[BNR ? EPV : 1], r1[BNR ? EPV : 1], r2[BNR ? EPV : 1];
     if constexpr (BNR) {
-      const int c0 = cur.co0 + (tid % SEGS) * EPV;
+      const int c0 = cur.co0 + sg * EPV;
 #pragma unroll
       for (int e = 0; e < EPV; ++e) {
         bmean[e] = s_bnc[c0 + e]; bistd[e] = s_bnc[p.Cout + c0 + e]; bsc[e] = s_bnc[2 * p.Cout + c0 + e]; bsh[e] = s_bnc[3 * p.Cout + c0 + e];
         r1[e] = 0.f; r2[e] = 0.f;
       }
     }
+    // destination of the thread's channel segment (the same for every unit)
+    const int co = cur.co0 + sg * EPV;
+    const bool to0 = co < p.D0;
+    T* const qb = to0 ? (T*)p.dst0 + co : (T*)p.dst1 + (co - p.D0);
+    const int qs = to0 ? p.Q0 : p.Q1;
+    const bool accum = to0 ? ((p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u) != 0u : p.acc1 != 0;
+    const bool any_accum = p.acc0_mask != 0u || p.acc1 != 0;     // uniform: plain launches never branch per unit
+    Vec16<T> vv[C::UO];
 #pragma unroll
     for (int k = 0; k < C::UO; ++k) {
-      const int u = tid + k * NT;
-      const int m = u / SEGS, sg = u - m * SEGS;
-      if (m < BM) {
-        const int gp = s_gpix[m];
-        if (gp >= 0) {
-          const int co = cur.co0 + sg * EPV;
-          T* q; bool accum;
-          if (co < p.D0) {
-            q = (T*)p.dst0 + (size_t)gp * p.Q0 + co;
-            accum = (p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u;
-          } else {
-            q = (T*)p.dst1 + (size_t)gp * p.Q1 + (co - p.D0);
-            accum = p.acc1 != 0;
-          }
-          Vec16<T> v = ld16(&s_out[m * OS + sg * EPV]);
-          if (accum) {
-            const Vec16<T> o = ld16(q);
+      const int m = m0 + k * (NT / SEGS);
+      vv[k] = ld16(&s_out[(m < BM ? m : 0) * OS + sg * EPV]);
+    }
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + o.get(e));
-          }
-          st16(q, v);
-          if constexpr (BNR) {
-            const Vec16<T> yv = byv[k];
+    for (int k = 0; k < C::UO; ++k) {
+      if (gpu[k] >= 0) {
+        T* const q = qb + (size_t)gpu[k] * qs;
+        Vec16<T> v = vv[k];
+        if (any_accum && accum) {
+          const Vec16<T> o = ld16(q);
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-              const float yy = yv.get(e);
-              const float dz = __builtin_fmaf(yy, bsc[e], bsh[e]) > 0.f ? v.get(e) : 0.f;   // the stored (rounded) gradient
-              r1[e] += dz;
-              r2[e] += dz * ((yy - bmean[e]) * bistd[e]);
-            }
+          for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + o.get(e));
+        }
+        st16(q, v);
+        if constexpr (BNR) {
+          const Vec16<T> yv = byv[k];
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) {
+            const float yy = yv.get(e);
+            const float dz = __builtin_fmaf(yy, bsc[e], bsh[e]) > 0.f ? v.get(e) : 0.f;   // the stored (rounded) gradient
+            r1[e] += dz;
+            r2[e] += dz * ((yy - bmean[e]) * bistd[e]);
           }
         }
       }
@@ -519,6 +551,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   int cc = 0, c_hi = 0;
   int kb = 0;
   if constexpr (SK) { cc = cur.ks * p.nch / p.S; c_hi = (cur.ks + 1) * p.nch / p.S; kb = chunk_kb(cc); }
+  KSTAMP(2);
   load_regs(kb);
   bool first_chunk = true;
   // per-channel coefficient tables, AFTER the first tile's loads were issued (the two global-memory latencies overlap);
@@ -569,9 +602,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
     }
   }
 
+  KSTAMP(3);
   while (true) {
     __syncthreads();  // previous chunk's fragment reads / previous item's epilogue reads are done
+    KSTAMP(kst); ++kst;       // a: barrier passed
     write_lds(kb, LT != 0 && p.tf_store != nullptr && cur.co0 == 0);
+    KSTAMP(kst); ++kst;       // b: loads arrived, transformed, written to LDS
     if (first_chunk) {
       for (int m = tid; m < BM; m += NT) {
         const int code = s_mxy[m];
@@ -582,8 +618,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         }
         s_gpix[m] = gp;
       }
+      // (issued while no staging load is outstanding and consumed in the epilogue, a whole MFMA sweep later)
+      if (p.bias) {
+#pragma unroll
+        for (int b = 0; b < SN; ++b) biasr[b] = p.bias[cur.co0 + (wn * SN + b) * 32 + r];
+      }
     }
     __syncthreads();
+    KSTAMP(kst); ++kst;       // c: barrier passed
     // prefetch the next (item, chunk) into registers
     int nkb = kb + C::KC, nitem = item, ncc = cc + 1, nc_hi = c_hi;
     Item nxt = cur;
@@ -602,10 +644,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       if constexpr (SK) nkb = chunk_kb(ncc);
       load_regs(nkb);
     }
+    KSTAMP(kst); ++kst;       // d: next item decoded, loads issued
     sweep();
+    KSTAMP(kst); ++kst;       // e: MFMA sweep done
     first_chunk = false;
     if (last_chunk) {
       if constexpr (SK) epi_sk(cur); else epi_plain(cur, s_buf);
+      KSTAMP(kst); ++kst;     // f: epilogue done
       if (!have_next) break;
       cur = nxt; item = nitem; first_chunk = true;
     }
@@ -791,6 +836,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   }
   p.nItems = (int)items;
   p.invS = fastdiv_inv(p.S); p.invCoT = fastdiv_inv(p.nCoT); p.invTX = fastdiv_inv(p.tilesX); p.invTY = fastdiv_inv(p.tilesY);
+  p.invTHW = fastdiv_inv(g.TH * g.TW); p.invTW = fastdiv_inv(g.TW); p.invHH2HW2 = fastdiv_inv((g.TH + 2) * (g.TW + 2)); p.invHW2 = fastdiv_inv(g.TW + 2);
   // persistent grid: resident workgroups only, item counts balanced across them
   const size_t dyn = sizeof(float) * (size_t)conv_coef_floats(lt, p.Cin, bnr && p.S == 1, p.Cout);
   const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN + dyn;

@@ -73,6 +73,7 @@ def conv(H, c0, c1, cout, lt=0, bnr=False, d1=0, ws=None):
     keep.append(d)
     return time_graph(lambda: L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream())))
 
+ONLY = os.environ.get("ONLY")   # "i,j,k": level, column, kind (0 conv1, 1 conv2, 2 dgrad2, 3 dgrad1) - one case, R*13 eager-ish launches (for PC sampling)
 print("%-8s %10s %10s %10s %10s   (us per launch, bf16 N=%d %dx%d)" % ("block", "conv1", "conv2", "dgrad2", "dgrad1", N, HW, HW))
 tot = [0.0] * 4
 for i in range(5):
@@ -83,6 +84,38 @@ for i in range(5):
             c0, c1 = (32 if i == 0 else NBF[i - 1]), 0
         else:
             c0, c1 = j * f, NBF[i + 1]
+        if ONLY:
+            oi, oj, ok = (int(v) for v in ONLY.split(","))
+            if (oi, oj) != (i, j): continue
+            v = [lambda: conv(H, c0, c1, f, ws=ws), lambda: conv(H, f, 0, f, lt=1, ws=ws), lambda: conv(H, f, 0, f, lt=2, bnr=True, ws=ws),
+                 lambda: conv(H, f, 0, c0 + c1, lt=2, d1=c1, ws=ws)][ok]()
+            print("B%d%d kind %d: %.1f us" % (i, j, ok, v))
+            if os.environ.get("KSTAMP"):
+                # diagnostic library (tools/kstamp_build.sh): phase stamps of wave 0 of the first WGS workgroups, ONE eager launch
+                import numpy as np
+                WGS = 2048
+                buf = torch.zeros(WGS * 32, dtype=torch.int64, device="cuda")
+                fn = L.lib().nunet_kstamp_set; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+                assert fn(buf.data_ptr(), WGS) == 0
+                d = [k for k in keep if isinstance(k, L.ConvDesc)][-1]
+                torch.cuda.synchronize()
+                L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream())); torch.cuda.synchronize()
+                st = buf.cpu().numpy().reshape(WGS, 32)
+                live = st[:, 0] > 0
+                st = st[live].astype(np.float64)
+                t0 = st[:, 0].min()
+                print("workgroups stamped:", int(live.sum()), " kernel span (cycles of s_memtime, 100 MHz):", (st.max() - t0))
+                names = ["entry", "tables", "coef0", "loop"] + [x + str(n) for n in range(5) for x in "abcdef"]
+                rel = st - t0
+                print("%-8s %10s %10s %10s   %s" % ("stamp", "median", "p10", "p90", "median delta to previous"))
+                prev = None
+                for k in range(32):
+                    col = rel[:, k][st[:, k] > 0]
+                    if col.size == 0: continue
+                    dl = "" if prev is None else "%.0f" % np.median((st[:, k] - st[:, prev])[(st[:, k] > 0) & (st[:, prev] > 0)])
+                    print("%-8s %10.0f %10.0f %10.0f   %s   (n=%d)" % (names[k] if k < len(names) else str(k), np.median(col), np.percentile(col, 10), np.percentile(col, 90), dl, col.size))
+                    prev = k
+            continue
         a = conv(H, c0, c1, f, ws=ws)
         b = conv(H, f, 0, f, lt=1, ws=ws)
         c = conv(H, f, 0, f, lt=2, bnr=True, ws=ws)
@@ -92,4 +125,4 @@ for i in range(5):
             dd = conv(H, f, 0, c0 + c1, lt=2, d1=c1, ws=ws)
         print("B%d%d      %10.1f %10.1f %10.1f %10.1f" % (i, j, a, b, c, dd))
         for k, v in enumerate((a, b, c, dd)): tot[k] += v
-print("sum      %10.1f %10.1f %10.1f %10.1f   total %.1f" % (*tot, sum(tot)))
+if not ONLY: print("sum      %10.1f %10.1f %10.1f %10.1f   total %.1f" % (*tot, sum(tot)))
