@@ -12,6 +12,7 @@
 //
 // MFMA shapes: 32x32x16 (bf16 / f16) and 32x32x2 (f32, exact fp32).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -174,7 +175,7 @@ extern "C" int nunet_kstamp_set(void* buf, int wgs) {
 #define KSTAMP(i) do {} while (0)
 #endif
 
-static inline int conv_coef_floats(int lt, int cin, bool bnr, int cout) { return (lt == 1 ? 2 : lt == 2 ? 4 : 0) * cin + (bnr ? 4 * cout : 0); }
+static inline int conv_coef_floats(int lt, int cin, bool bnr, int cout) { return (lt == 1 ? 2 : lt == 2 ? 4 : 0) * cin + (bnr ? 4 * cout : 0) + cout; }
 
 // Persistent kernel: each workgroup walks (tile, Cout-tile) items with stride gridDim.x.
 // The global loads of the NEXT (item, channel chunk) are issued into registers before the
@@ -196,10 +197,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   __shared__ int s_hxy[C::HPMAX];    // tile-invariant: packed (ni, hy, hx) of halo pixel, -1 unused
   __shared__ int s_gpix[BM];         // per item: global pixel of row m, -1 masked
   __shared__ float s_red[2 * WM * BN];
-  extern __shared__ __attribute__((aligned(16))) float s_coef[];   // LT tables [2 or 4][Cin], then BNR tables [4][Cout]
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];   // LT tables [2 or 4][Cin], then BNR tables [4][Cout], then the bias [Cout]
   T* const s_halo = s_buf;
   T* const s_w = s_buf + C::HALO_ELEMS;
   float* const s_bnc = s_coef + (LT == 1 ? 2 : LT == 2 ? 4 : 0) * p.Cin;
+  float* const s_bias = s_bnc + (BNR ? 4 : 0) * p.Cout;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -299,20 +301,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   }
   unsigned wco = 0u;                 // the loaded item's Cout tile: co0 * Cin elements, in bytes (uniform)
   auto set_ptrs = [&](const Item& it) { wco = (unsigned)(it.co0 * p.Cin * (int)sizeof(T)); };
-  auto load_regs = [&](int kb) {
+  // The staging loads of a chunk: uniform part (source, pitch, channel offset) once, then one 16-byte load per unit.
+  // The first chunk of a workgroup issues them back to back (load_regs); every later chunk's loads are spread over the
+  // MFMA sweep of the chunk before it (sweep<true>), one per step: a wave's 12 loads take ~16 clocks each of the CU's
+  // address/L1 path, and issued as a block they stall the wave for ~1200 clocks with the matrix pipe idle.
+  struct LoadCtx { const char* base; unsigned pb, cb, yb, ycb, wb; };
+  auto load_ctx = [&](int kb) {
+    LoadCtx c;
     const bool s0 = LT != 0 || kb < p.C0;
-    const char* const base = (const char*)(s0 ? p.src0 : p.src1);
-    const unsigned pb = (unsigned)(s0 ? p.P0 : p.P1) * (unsigned)sizeof(T);
-    const unsigned cb = (unsigned)((s0 ? kb : kb - p.C0) * (int)sizeof(T) + seg * 16);
-#pragma unroll
-    for (int k = 0; k < C::UH; ++k) {
-      const unsigned gp = hgp[k] < 0 ? 0u : (unsigned)hgp[k];
-      hreg[k].raw = *reinterpret_cast<const u32x4*>(base + (gp * pb + cb));
-      if constexpr (LT == 2) yreg[k].raw = *reinterpret_cast<const u32x4*>((const char*)p.tf_y + (gp * ((unsigned)p.tf_py * (unsigned)sizeof(T)) + (unsigned)(kb * (int)sizeof(T) + seg * 16)));
+    c.base = (const char*)(s0 ? p.src0 : p.src1);
+    c.pb = (unsigned)(s0 ? p.P0 : p.P1) * (unsigned)sizeof(T);
+    c.cb = (unsigned)((s0 ? kb : kb - p.C0) * (int)sizeof(T) + seg * 16);
+    c.yb = (unsigned)p.tf_py * (unsigned)sizeof(T);
+    c.ycb = (unsigned)(kb * (int)sizeof(T) + seg * 16);
+    c.wb = (unsigned)(kb * (int)sizeof(T)) + wco;
+    return c;
+  };
+  constexpr int NU = C::UH + C::UW;
+  auto load_unit = [&](const LoadCtx& c, int u) {       // u is a compile-time constant after unrolling
+    if (u < C::UH) {
+      const unsigned gp = hgp[u] < 0 ? 0u : (unsigned)hgp[u];
+      hreg[u].raw = *reinterpret_cast<const u32x4*>(c.base + (gp * c.pb + c.cb));
+      if constexpr (LT == 2) yreg[u].raw = *reinterpret_cast<const u32x4*>((const char*)p.tf_y + (gp * c.yb + c.ycb));
+    } else {
+      wreg[u - C::UH].raw = *reinterpret_cast<const u32x4*>((const char*)p.w + (woff[u - C::UH] + c.wb));
     }
-    const unsigned wb = (unsigned)(kb * (int)sizeof(T)) + wco;
+  };
+  auto load_regs = [&](int kb) {
+    const LoadCtx c = load_ctx(kb);
 #pragma unroll
-    for (int k = 0; k < C::UW; ++k) wreg[k].raw = *reinterpret_cast<const u32x4*>((const char*)p.w + (woff[k] + wb));
+    for (int u = 0; u < NU; ++u) load_unit(c, u);
   };
   // registers -> LDS; LT kernels transform the input on the way. `kb` / `store` belong to the chunk held in the
   // registers (hgp[] still describes its item: the next item's pixels are mapped only after this write).
@@ -363,8 +381,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   // K-split kernels walk channel CHUNKS [c_lo, c_hi) of their slice; plain kernels walk channels
   auto chunk_kb = [&](int c) { return c < p.nch0 ? c * C::KC : p.C0 + (c - p.nch0) * C::KC; };
   constexpr int NSTEP = 9 * KS;
-  // fragments of the next step are read while the current one multiplies
-  auto sweep = [&]() {
+  // fragments of the next step are read while the current one multiplies; LOADS: the next chunk's staging loads are
+  // issued one per step between the fragment reads and the MFMAs (the scheduling barriers keep them there)
+  auto sweep = [&](auto LOADS, const LoadCtx& lc) {
+    constexpr bool WITH_LOADS = decltype(LOADS)::value;
     typename M::Frag fa[2][SM], fb[2][SN];
 #pragma unroll
     for (int a = 0; a < SM; ++a) fa[0][a] = M::load(&s_halo[abase[a] + toff[0]]);
@@ -380,10 +400,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
 #pragma unroll
         for (int b = 0; b < SN; ++b) fb[cu ^ 1][b] = M::load(&s_w[bbase + (tap * BN + b * 32) * PS + ks * 16]);
       }
+      if constexpr (WITH_LOADS) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          if ((u * NSTEP) / NU == j) load_unit(lc, u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int a = 0; a < SM; ++a)
 #pragma unroll
         for (int b = 0; b < SN; ++b) M::mma(acc[a][b], fa[cu][a], fb[cu][b]);
+      if constexpr (WITH_LOADS) __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto epi_sk = [&](const Item& cur) {
@@ -404,14 +431,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       }
     }
   };
-  float biasr[SN];                   // bias of this thread's output channels for the item being computed (set with s_gpix)
-#pragma unroll
-  for (int b = 0; b < SN; ++b) biasr[b] = 0.f;
   static_assert(SM * 16 <= 32, "row-validity mask of the epilogue is one 32-bit word");
   auto epi_plain = [&](const Item& cur, T* const s_out) {
     // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
-    // Nothing in here waits on a global LOAD unless a destination accumulates: the bias was fetched when the item
-    // started, and a wait would also drain the next item's staging loads already in flight (the counter is in-order).
+    // Nothing in here waits on a global LOAD unless a destination accumulates (the bias sits in an LDS table since the
+    // prologue): a wait would also drain the next item's staging loads already in flight (the counter is in-order).
     constexpr int SEGS = BN / EPV;
     const int sg = tid % SEGS, m0 = tid / SEGS;       // NT % SEGS == 0: every store unit of a thread has the same channel segment
     // BNR: the y1 vectors of this thread's store units are requested NOW, so their latency hides under
@@ -436,11 +460,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) rowmask |= (s_gpix[(wm * SM + a) * 32 + acc_row(i, h)] >= 0 ? 1u : 0u) << (a * 16 + i);
     }
+    KSTAMP(kst); ++kst;       // g: row masks / unit pixels read
     __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
+    KSTAMP(kst); ++kst;       // h: barrier passed
 #pragma unroll
     for (int b = 0; b < SN; ++b) {
       const int cl = (wn * SN + b) * 32 + r;  // channel within the tile
-      const float bias = biasr[b];
+      const float bias = s_bias[cur.co0 + cl];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int a = 0; a < SM; ++a) {
@@ -460,7 +486,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         if (h == 0) { s_red[(wm * BN + cl) * 2 + 0] = s1; s_red[(wm * BN + cl) * 2 + 1] = s2; }
       }
     }
+    KSTAMP(kst); ++kst;       // i: accumulators transposed into LDS
     __syncthreads();
+    KSTAMP(kst); ++kst;       // j: barrier passed
     // BNR: the BN-backward partial sums of the thread's 8 channels live in registers across the store loop
     float bmean[BNR ? EPV : 1], bistd[BNR ? EPV : 1], bsc[BNR ? EPV : 1], bsh[BNR ? EPV : 1], r1[BNR ? EPV : 1], r2[BNR ? EPV : 1];
     if constexpr (BNR) {
@@ -475,7 +503,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
     const int co = cur.co0 + sg * EPV;
     const bool to0 = co < p.D0;
     T* const qb = to0 ? (T*)p.dst0 + co : (T*)p.dst1 + (co - p.D0);
-    const int qs = to0 ? p.Q0 : p.Q1;
+    // (readfirstlane: a per-lane select between two kernel arguments otherwise becomes a per-lane LOAD from the
+    //  argument segment, and the wait for it drains the staging loads in flight)
+    const int qs = to0 ? __builtin_amdgcn_readfirstlane(p.Q0) : __builtin_amdgcn_readfirstlane(p.Q1);
     const bool accum = to0 ? ((p.acc0_mask >> (p.slot_w > 0 ? fastdiv(co, p.inv_slot_w) : 0)) & 1u) != 0u : p.acc1 != 0;
     const bool any_accum = p.acc0_mask != 0u || p.acc1 != 0;     // uniform: plain launches never branch per unit
     Vec16<T> vv[C::UO];
@@ -507,6 +537,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         }
       }
     }
+    KSTAMP(kst); ++kst;       // k: stores issued
     if constexpr (BNR) {
       // lanes that share a channel segment (lane % SEGS) are summed with xor-shuffles, the four waves
       // through a small LDS table (fixed order), then one fixed-point add per channel and sum
@@ -556,6 +587,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   bool first_chunk = true;
   // per-channel coefficient tables, AFTER the first tile's loads were issued (the two global-memory latencies overlap);
   // the barrier at the top of the loop orders them before the first write_lds / epilogue
+  for (int c = tid; c < p.Cout; c += NT) s_bias[c] = p.bias ? p.bias[c] : 0.f;
   if constexpr (BNR) {
     for (int c = tid; c < p.Cout; c += NT) {
       const float mean = p.bn_mi[c], istd = p.bn_mi[p.Cout + c];
@@ -618,11 +650,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         }
         s_gpix[m] = gp;
       }
-      // (issued while no staging load is outstanding and consumed in the epilogue, a whole MFMA sweep later)
-      if (p.bias) {
-#pragma unroll
-        for (int b = 0; b < SN; ++b) biasr[b] = p.bias[cur.co0 + (wn * SN + b) * 32 + r];
-      }
     }
     __syncthreads();
     KSTAMP(kst); ++kst;       // c: barrier passed
@@ -642,10 +669,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
     }
     if (have_next) {
       if constexpr (SK) nkb = chunk_kb(ncc);
-      load_regs(nkb);
     }
-    KSTAMP(kst); ++kst;       // d: next item decoded, loads issued
-    sweep();
+    const LoadCtx lc = load_ctx(nkb);
+    KSTAMP(kst); ++kst;       // d: next item decoded
+    if (have_next) sweep(std::true_type{}, lc); else sweep(std::false_type{}, lc);
     KSTAMP(kst); ++kst;       // e: MFMA sweep done
     first_chunk = false;
     if (last_chunk) {

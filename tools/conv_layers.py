@@ -105,7 +105,7 @@ for i in range(5):
                 st = st[live].astype(np.float64)
                 t0 = st[:, 0].min()
                 print("workgroups stamped:", int(live.sum()), " kernel span (cycles of s_memtime, 100 MHz):", (st.max() - t0))
-                names = ["entry", "tables", "coef0", "loop"] + [x + str(n) for n in range(5) for x in "abcdef"]
+                names = ["entry", "tables", "coef0", "loop"] + [x + str(n) for n in range(5) for x in "abcdeghijkf"]
                 rel = st - t0
                 print("%-8s %10s %10s %10s   %s" % ("stamp", "median", "p10", "p90", "median delta to previous"))
                 prev = None
