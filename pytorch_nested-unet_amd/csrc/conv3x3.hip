@@ -29,6 +29,7 @@ template <> struct Mma<bf16_t> {
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
+  static __device__ __forceinline__ void sink(const Frag& a) { asm volatile("" :: "v"(a)); }   // diagnostic builds
 };
 template <> struct Mma<f16_t> {
   typedef f16x8 Frag;
@@ -36,6 +37,7 @@ template <> struct Mma<f16_t> {
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
   }
+  static __device__ __forceinline__ void sink(const Frag& a) { asm volatile("" :: "v"(a)); }
 };
 template <> struct Mma<float> {
   struct Frag { f32x4 lo, hi; };
@@ -51,6 +53,7 @@ template <> struct Mma<float> {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[t], b.hi[t], acc, 0, 0, 0);
   }
+  static __device__ __forceinline__ void sink(const Frag& a) { asm volatile("" :: "v"(a.lo), "v"(a.hi)); }
 };
 
 // row of accumulator register `reg` for lane half h (32x32 C/D layout)
@@ -170,9 +173,19 @@ extern "C" int nunet_kstamp_set(void* buf, int wgs) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_kstamp), &buf, sizeof(buf)) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_kstamp_wgs), &wgs, sizeof(wgs)) != hipSuccess;
 }
-#define KSTAMP(i) do { if (threadIdx.x == 0 && (int)blockIdx.x < g_kstamp_wgs && (i) < 32) g_kstamp[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KSTAMP(i) do { if (threadIdx.x == 0 && (int)blockIdx.x < g_kstamp_wgs && (i) < 30) g_kstamp[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// slots 30 / 31: the chip-wide 100 MHz counter at workgroup entry / exit (s_memtime is per-CU and not comparable across workgroups)
+#define KSTAMP_RT(i) do { if (threadIdx.x == 0 && (int)blockIdx.x < g_kstamp_wgs) g_kstamp[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define KSTAMP(i) do {} while (0)
+#define KSTAMP_RT(i) do {} while (0)
+#endif
+
+// Diagnostic build only (-DNUNET_ABLATE=bits, tools/ablate_build.sh): parts of the conv kernel are left out to see which
+// resource bounds a layer (results are wrong by construction). 1 no MFMA | 2 no fragment reads | 4 no staging loads after
+// the first | 8 no LDS staging writes after the first | 16 no epilogue | 32 no statistics atomics | 64 no output stores | 128 no y1 loads | 256 no BNR math | 512 no BNR cross-lane reduce | 1024 no transposition (LDS writes + stats) 
+#ifndef NUNET_ABLATE
+#define NUNET_ABLATE 0
 #endif
 
 static inline int conv_coef_floats(int lt, int cin, bool bnr, int cout) { return (lt == 1 ? 2 : lt == 2 ? 4 : 0) * cin + (bnr ? 4 * cout : 0) + cout; }
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   const int HW2 = p.TW + 2, HH2 = p.TH + 2;
   const int HP = p.NI * HH2 * HW2;
   const int THW = p.TH * p.TW;
-  KSTAMP(0);
+  KSTAMP(0); KSTAMP_RT(30);
   [[maybe_unused]] int kst = 4;   // NUNET_KSTAMP: next stamp slot of the loop
 
   // (divisions by launch constants as multiplies by host-computed inverses: the generic 32-bit division is ~30 instructions,
@@ -385,32 +398,37 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   // issued one per step between the fragment reads and the MFMAs (the scheduling barriers keep them there)
   auto sweep = [&](auto LOADS, const LoadCtx& lc) {
     constexpr bool WITH_LOADS = decltype(LOADS)::value;
-    typename M::Frag fa[2][SM], fb[2][SN];
+    // Fragment reads run PD steps ahead of the MFMAs that consume them (PD + 1 register buffers). Measured: 2 or 3
+    // steps ahead cost 12-30 registers and change no layer's time (tools/conv_layers.py), so one step it is.
+    constexpr int PD = 1;
+    constexpr int NB = PD + 1;
+    typename M::Frag fa[NB][SM], fb[NB][SN];
+    auto read_step = [&](int j) {                 // j: compile-time after unrolling
+      const int tap = j / KS, ks = j % KS, bu = j % NB;
 #pragma unroll
-    for (int a = 0; a < SM; ++a) fa[0][a] = M::load(&s_halo[abase[a] + toff[0]]);
+      for (int a = 0; a < SM; ++a) fa[bu][a] = M::load(&s_halo[abase[a] + toff[tap] + ks * 16]);
 #pragma unroll
-    for (int b = 0; b < SN; ++b) fb[0][b] = M::load(&s_w[bbase + (b * 32) * PS]);
+      for (int b = 0; b < SN; ++b) fb[bu][b] = M::load(&s_w[bbase + (tap * BN + b * 32) * PS + ks * 16]);
+    };
+#pragma unroll
+    for (int j = 0; j < PD; ++j) read_step(j);
 #pragma unroll
     for (int j = 0; j < NSTEP; ++j) {
-      const int cu = j & 1;
-      if (j + 1 < NSTEP) {
-        const int tap = (j + 1) / KS, ks = (j + 1) % KS;
-#pragma unroll
-        for (int a = 0; a < SM; ++a) fa[cu ^ 1][a] = M::load(&s_halo[abase[a] + toff[tap] + ks * 16]);
-#pragma unroll
-        for (int b = 0; b < SN; ++b) fb[cu ^ 1][b] = M::load(&s_w[bbase + (tap * BN + b * 32) * PS + ks * 16]);
-      }
-      if constexpr (WITH_LOADS) {
+      if (j + PD < NSTEP && !(NUNET_ABLATE & 2)) read_step(j + PD);
+      if constexpr (WITH_LOADS && !(NUNET_ABLATE & 4)) {
 #pragma unroll
         for (int u = 0; u < NU; ++u)
           if ((u * NSTEP) / NU == j) load_unit(lc, u);
-        __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < SM; ++a)
 #pragma unroll
-        for (int b = 0; b < SN; ++b) M::mma(acc[a][b], fa[cu][a], fb[cu][b]);
-      if constexpr (WITH_LOADS) __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < SN; ++b) {
+          if constexpr (NUNET_ABLATE & 1) { M::sink(fa[j % NB][a]); M::sink(fb[j % NB][b]); }
+          else M::mma(acc[a][b], fa[j % NB][a], fb[j % NB][b]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto epi_sk = [&](const Item& cur) {
@@ -432,25 +450,33 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
     }
   };
   static_assert(SM * 16 <= 32, "row-validity mask of the epilogue is one 32-bit word");
+  // BNR: the y1 vectors of this thread's store units. They are requested BEFORE the last chunk's sweep, i.e. before the
+  // next item's staging loads: loads return in order, so the epilogue's wait for them leaves those staging loads in
+  // flight (requested in the epilogue, behind them, the wait drained all twelve and cost a memory latency per item).
+  Vec16<T> byv[BNR ? C::UO : 1];
+  auto issue_byv = [&](const Item& cur) {
+    if constexpr (BNR) {
+      constexpr int SEGS = BN / EPV;
+      const int sg = tid % SEGS, m0 = tid / SEGS;
+#pragma unroll
+      for (int k = 0; k < C::UO; ++k) {
+        const int m = m0 + k * (NT / SEGS);
+        const int gp = m < BM ? s_gpix[m] : -1;
+        byv[k] = ld16((const T*)p.bn_y + (size_t)(gp < 0 ? 0 : gp) * p.bn_py + cur.co0 + sg * EPV);
+      }
+    }
+  };
   auto epi_plain = [&](const Item& cur, T* const s_out) {
     // ---- epilogue: bias, BN partial sums from registers, LDS transpose, 16-byte stores ----
     // Nothing in here waits on a global LOAD unless a destination accumulates (the bias sits in an LDS table since the
     // prologue): a wait would also drain the next item's staging loads already in flight (the counter is in-order).
     constexpr int SEGS = BN / EPV;
     const int sg = tid % SEGS, m0 = tid / SEGS;       // NT % SEGS == 0: every store unit of a thread has the same channel segment
-    // BNR: the y1 vectors of this thread's store units are requested NOW, so their latency hides under
-    // the accumulator -> LDS transposition below instead of being exposed once per unit in the store loop
-    Vec16<T> byv[BNR ? C::UO : 1];
     int gpu[C::UO];
 #pragma unroll
     for (int k = 0; k < C::UO; ++k) {
       const int m = m0 + k * (NT / SEGS);
       gpu[k] = m < BM ? s_gpix[m] : -1;
-    }
-    if constexpr (BNR) {
-#pragma unroll
-      for (int k = 0; k < C::UO; ++k)
-        if (gpu[k] >= 0) byv[k] = ld16((const T*)p.bn_y + (size_t)gpu[k] * p.bn_py + cur.co0 + sg * EPV);
     }
     // which of this thread's accumulator rows are pixels of the image (all 16*SM reads in flight at once)
     unsigned rowmask = 0u;
@@ -474,7 +500,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         for (int i = 0; i < 16; ++i) {
           const int m = (wm * SM + a) * 32 + acc_row(i, h);
           const T tv = from_f32<T>(acc[a][b][i] + bias);
-          s_out[m * OS + cl] = tv;
+          if (!(NUNET_ABLATE & 1024)) s_out[m * OS + cl] = tv;
           const float d = ((rowmask >> (a * 16 + i)) & 1u) ? to_f32(tv) - bias : 0.f;
           s1 += d; s2 += d * d;
           acc[a][b][i] = 0.f;
@@ -524,8 +550,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
 #pragma unroll
           for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + o.get(e));
         }
-        st16(q, v);
-        if constexpr (BNR) {
+        if (!(NUNET_ABLATE & 64)) st16(q, v); else asm volatile("" :: "v"(v.raw));
+        if constexpr (BNR && !(NUNET_ABLATE & 256)) {
           const Vec16<T> yv = byv[k];
 #pragma unroll
           for (int e = 0; e < EPV; ++e) {
@@ -538,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       }
     }
     KSTAMP(kst); ++kst;       // k: stores issued
-    if constexpr (BNR) {
+    if constexpr (BNR && !(NUNET_ABLATE & 512)) {
       // lanes that share a channel segment (lane % SEGS) are summed with xor-shuffles, the four waves
       // through a small LDS table (fixed order), then one fixed-point add per channel and sum
 #pragma unroll
@@ -561,7 +587,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         float sum = 0.f;
 #pragma unroll
         for (int wv = 0; wv < WM * WN; ++wv) sum += s_bn[(wv * 2 + vsel) * BN + c];
-        fx_add(p.bn_sums + ((size_t)((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum);
+        if (!(NUNET_ABLATE & 32)) fx_add(p.bn_sums + ((size_t)((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum); else asm volatile("" :: "v"(sum));
       }
     }
     if (p.stats) {
@@ -570,7 +596,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < WM; ++k) sum += s_red[(k * BN + c) * 2 + vsel];
-        fx_add(p.stats + ((size_t)((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum);
+        if (!(NUNET_ABLATE & 32)) fx_add(p.stats + ((size_t)((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum); else asm volatile("" :: "v"(sum));
       }
     }
   };
@@ -638,7 +664,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   while (true) {
     __syncthreads();  // previous chunk's fragment reads / previous item's epilogue reads are done
     KSTAMP(kst); ++kst;       // a: barrier passed
-    write_lds(kb, LT != 0 && p.tf_store != nullptr && cur.co0 == 0);
+    if (!(NUNET_ABLATE & 8) || (item == (int)blockIdx.x && first_chunk)) write_lds(kb, LT != 0 && p.tf_store != nullptr && cur.co0 == 0);
     KSTAMP(kst); ++kst;       // b: loads arrived, transformed, written to LDS
     if (first_chunk) {
       for (int m = tid; m < BM; m += NT) {
@@ -671,14 +697,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       if constexpr (SK) nkb = chunk_kb(ncc);
     }
     const LoadCtx lc = load_ctx(nkb);
+    if constexpr (BNR && !SK && !(NUNET_ABLATE & 128)) { if (last_chunk) issue_byv(cur); }
     KSTAMP(kst); ++kst;       // d: next item decoded
     if (have_next) sweep(std::true_type{}, lc); else sweep(std::false_type{}, lc);
     KSTAMP(kst); ++kst;       // e: MFMA sweep done
     first_chunk = false;
     if (last_chunk) {
-      if constexpr (SK) epi_sk(cur); else epi_plain(cur, s_buf);
+      if constexpr (NUNET_ABLATE & 16) {
+#pragma unroll
+        for (int a = 0; a < SM; ++a)
+#pragma unroll
+          for (int b = 0; b < SN; ++b) asm volatile("" : "+v"(acc[a][b]));
+      } else if constexpr (SK) epi_sk(cur); else epi_plain(cur, s_buf);
       KSTAMP(kst); ++kst;     // f: epilogue done
-      if (!have_next) break;
+      if (!have_next) { KSTAMP_RT(31); break; }
       cur = nxt; item = nitem; first_chunk = true;
     }
     kb = nkb; cc = ncc; c_hi = nc_hi;
@@ -905,7 +937,8 @@ template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream
   // items than the chip has CUs; there the 128 x 32 tile (4 workgroups per CU, twice the items) wins by up to 2x and
   // needs no K-split. It also wins for the plain / BN-forward Cout = 32 convs of the first level (one wave per SIMD
   // with the 256-pixel tile). With the BN-backward input transform the small tile loses: every Cout tile repeats the
-  // transform of its input tile.
+  // transform of its input tile. Also measured and not kept: the same tiles on 8 waves (32 x 32 per wave: every layer
+  // slower, up to 1.35x), one workgroup per CU to leave room for another lane's kernel (-4 % on the step).
   const long px = (long)d->N * d->H * d->W;
   const long items_std = cout % 64 == 0 ? ceil_div64(px, 128) * (cout / 64) : ceil_div64(px, 256) * (cout / 32);
   const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD);

@@ -104,12 +104,17 @@ for i in range(5):
                 live = st[:, 0] > 0
                 st = st[live].astype(np.float64)
                 t0 = st[:, 0].min()
-                print("workgroups stamped:", int(live.sum()), " kernel span (cycles of s_memtime, 100 MHz):", (st.max() - t0))
+                # slots 30 / 31: chip-wide 100 MHz counter at workgroup entry / exit
+                rt0, rt1 = st[:, 30], st[:, 31]
+                base = rt0.min()
+                print("workgroups stamped: %d | entry after first (us): p50 %.2f p90 %.2f max %.2f | exit (us): p10 %.2f p50 %.2f p90 %.2f max %.2f | life (us) p50 %.2f | s_memtime cycles per us: %.0f"
+                      % (live.sum(), *(np.percentile(rt0 - base, q) / 100 for q in (50, 90, 100)), *(np.percentile(rt1 - base, q) / 100 for q in (10, 50, 90, 100)),
+                         np.median(rt1 - rt0) / 100, np.median((st[:, :30].max(axis=1) - st[:, 0]) / np.maximum(rt1 - rt0, 1) * 100)))
                 names = ["entry", "tables", "coef0", "loop"] + [x + str(n) for n in range(5) for x in "abcdeghijkf"]
                 rel = st - t0
                 print("%-8s %10s %10s %10s   %s" % ("stamp", "median", "p10", "p90", "median delta to previous"))
                 prev = None
-                for k in range(32):
+                for k in range(30):
                     col = rel[:, k][st[:, k] > 0]
                     if col.size == 0: continue
                     dl = "" if prev is None else "%.0f" % np.median((st[:, k] - st[:, prev])[(st[:, k] > 0) & (st[:, prev] > 0)])
