@@ -56,6 +56,12 @@ template <> struct Mma<float> {
   static __device__ __forceinline__ void sink(const Frag& a) { asm volatile("" :: "v"(a.lo), "v"(a.hi)); }
 };
 
+// value of the lane N places further on in the same row of 16 lanes (wrapping): after `x += dpp_row_ror<4>(x); x += dpp_row_ror<8>(x)`
+// every lane holds the sum over the four lanes of its row that share lane % 4 (and with <8> alone: over lane % 8 pairs)
+template <int N> __device__ __forceinline__ float dpp_row_ror(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
+
 // row of accumulator register `reg` for lane half h (32x32 C/D layout)
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -516,14 +522,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
     __syncthreads();
     KSTAMP(kst); ++kst;       // j: barrier passed
     // BNR: the BN-backward partial sums of the thread's 8 channels live in registers across the store loop
-    float bmean[BNR ? EPV : 1], bistd[BNR ? EPV : 1], bsc[BNR ? EPV : 1], bsh[BNR ? EPV : 1], r1[BNR ? EPV : 1], r2[BNR ? EPV : 1];
+    typedef typename FV<T>::type V;
+    V bmean, bistd, bsc, bsh, r1 = V(0.f), r2 = V(0.f);
     if constexpr (BNR) {
       const int c0 = cur.co0 + sg * EPV;
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        bmean[e] = s_bnc[c0 + e]; bistd[e] = s_bnc[p.Cout + c0 + e]; bsc[e] = s_bnc[2 * p.Cout + c0 + e]; bsh[e] = s_bnc[3 * p.Cout + c0 + e];
-        r1[e] = 0.f; r2[e] = 0.f;
-      }
+      bmean = ldf<T>(&s_bnc[c0]); bistd = ldf<T>(&s_bnc[p.Cout + c0]); bsc = ldf<T>(&s_bnc[2 * p.Cout + c0]); bsh = ldf<T>(&s_bnc[3 * p.Cout + c0]);
     }
     // destination of the thread's channel segment (the same for every unit)
     const int co = cur.co0 + sg * EPV;
@@ -545,21 +548,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       if (gpu[k] >= 0) {
         T* const q = qb + (size_t)gpu[k] * qs;
         Vec16<T> v = vv[k];
-        if (any_accum && accum) {
-          const Vec16<T> o = ld16(q);
-#pragma unroll
-          for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + o.get(e));
-        }
+        if (any_accum && accum) v = vec_from_f<T>(vec_to_f<T>(v) + vec_to_f<T>(ld16(q)));
         if (!(NUNET_ABLATE & 64)) st16(q, v); else asm volatile("" :: "v"(v.raw));
         if constexpr (BNR && !(NUNET_ABLATE & 256)) {
-          const Vec16<T> yv = byv[k];
-#pragma unroll
-          for (int e = 0; e < EPV; ++e) {
-            const float yy = yv.get(e);
-            const float dz = __builtin_fmaf(yy, bsc[e], bsh[e]) > 0.f ? v.get(e) : 0.f;   // the stored (rounded) gradient
-            r1[e] += dz;
-            r2[e] += dz * ((yy - bmean[e]) * bistd[e]);
-          }
+          // whole-vector math (the element accessors cost ~3x the instructions): dz = the stored (rounded) gradient
+          // where the forward activation was positive; sums of dz and dz * xhat
+          const V yf = vec_to_f<T>(byv[k]);
+          const V dz = __builtin_elementwise_fma(yf, bsc, bsh) > V(0.f) ? vec_to_f<T>(v) : V(0.f);
+          r1 += dz;
+          r2 += dz * ((yf - bmean) * bistd);
         }
       }
     }
@@ -567,10 +564,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
     if constexpr (BNR && !(NUNET_ABLATE & 512)) {
       // lanes that share a channel segment (lane % SEGS) are summed with xor-shuffles, the four waves
       // through a small LDS table (fixed order), then one fixed-point add per channel and sum
+      // (strides 4 and 8 stay inside a row of 16 lanes: DPP row rotates, no LDS crossbar round trip; 16 and 32 shuffle)
 #pragma unroll
       for (int off = SEGS; off < 64; off <<= 1) {
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) { r1[e] += __shfl_xor(r1[e], off); r2[e] += __shfl_xor(r2[e], off); }
+        for (int e = 0; e < EPV; ++e) {
+          if (off == 4) { r1[e] += dpp_row_ror<4>(r1[e]); r2[e] += dpp_row_ror<4>(r2[e]); }
+          else if (off == 8) { r1[e] += dpp_row_ror<8>(r1[e]); r2[e] += dpp_row_ror<8>(r2[e]); }
+          else { r1[e] += __shfl_xor(r1[e], off); r2[e] += __shfl_xor(r2[e], off); }
+        }
       }
       __syncthreads();                                   // s_out reads of the store loop are done
       float* s_bn = reinterpret_cast<float*>(s_buf);     // [waves][2][BN]
