@@ -1509,7 +1509,12 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       int wl = wlane, r_gate = -1;     // (measured +1.9 % on the step)
       if (!P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
       S.add(wl, 1, 0.f, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up, r_gate}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
-            [=](hipStream_t ls) { g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w1, &w2, ls); g_prof_alg_cin = 0; return r; });
+            [=](hipStream_t ls) {
+              g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w1, &w2, ls); g_prof_alg_cin = 0;
+              // the block's K-split slabs are summed right behind it on the same lane: 15 small launches hidden beside the
+              // rest of the pass instead of one 58 us launch over all layers after the join, with nothing beside it
+              return r ? r : launch_reduce(P, arena, k, k, ls);
+            });
     }
     // "bucket 0 complete" (data-parallel exchange beside the rest of the backward pass, nunet_plan_bucket0_*): on the otherwise
     // unused lane 4, ops that read every gradient resource of the phase-1 nodes and the heads; the last one sums the phase's
@@ -1524,8 +1529,6 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
         S.name("b0rdy");
         S.add_v(4, 1, 0.f, rs.data() + q, (int)std::min<size_t>(10, rs.size() - q), [=](hipStream_t ls) {
           if (!last) return (int)NUNET_OK;
-          int r = launch_reduce(P, arena, k_split, nnodes - 1, ls);
-          if (r) return r;
           hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
           (void)hipStreamIsCapturing(ls, &cs);
           if (cs == hipStreamCaptureStatusActive) return graph_record_external(ls, ev);
@@ -1540,11 +1543,6 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   S.join();
   if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_backward: lane scheduler overflow (capture stream pool / dependency lists)"); rc = NUNET_EINVAL; }
   if (rc) return rc;
-  // slab sums of the nodes this call covered (phase-1 nodes were already reduced inside the pass when bucket 0 is signalled there)
-  if (phases & 3) {
-    const int lo = k_lo, hi = (b0_inside && S.multi) ? k_split - 1 : k_hi;
-    if (hi >= lo) CK(launch_reduce(P, arena, lo, hi, st));
-  }
   if (!(phases & 4)) return NUNET_OK;
   P->utab.accumulate = accumulate;
   ProfScope ps(PC_UNPACK, 0, (double)P->nparams * (accumulate ? 12 : 8), st);
