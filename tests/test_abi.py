@@ -32,6 +32,22 @@ def test_header_symbols_all_exported_and_bound(lib):
     assert lib.nunet_version() >= 100
 
 
+def test_product_library_carries_no_diagnostic_build(lib):
+    """The conv kernel source has two compile-time diagnostic modes (-DNUNET_KSTAMP: in-kernel phase stamps,
+    -DNUNET_ABLATE=bits: parts of the kernel compiled out; tools/kstamp_build.sh, tools/ablate_build.sh write their
+    libraries under tools/_diag/). The product library must be built with neither: it exports nothing but what
+    include/nunet.h declares (the stamp build adds nunet_kstamp_set), and the Makefile passes no such define."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (nunet_[a-z0-9_]+)", out))
+    hdr = open(os.path.join(ROOT, "include", "nunet.h")).read()
+    declared = set(re.findall(r"\b(nunet_[a-z0-9_]+)\s*\(", hdr)) - {"nunet_plan"}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    mk = open(os.path.join(os.path.dirname(L.LIB_PATH), "csrc", "Makefile")).read()
+    assert "NUNET_KSTAMP" not in mk and "NUNET_ABLATE" not in mk
+    assert os.environ.get("NUNET_LIB_PATH") is None or "_diag" not in os.environ["NUNET_LIB_PATH"]
+
+
 def test_plan_layout_matches_reference_state_dict(lib):
     """Host-only: the plan's flat parameter layout equals the reference parameters() order/size
     (9,163,329 params w/o DS, 9,163,428 with)."""
