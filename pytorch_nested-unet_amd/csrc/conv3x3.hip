@@ -1076,7 +1076,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
   }
   __syncthreads();
 
-  // Tile-invariant part of every staging unit's address, computed ONCE: in-kernel cycle stamps (tools/wgrad_stamps.py)
+  // Tile-invariant part of every staging unit's address, computed ONCE: in-kernel cycle stamps (round 2, the method of tools/kstamp_build.sh)
   // showed the per-tile address generation (seven map_pixel() calls with 64-bit pointer arithmetic per thread) at
   // 2300 cycles - more than the tile's MFMAs and fragment reads together (1300-2100). A unit is (image-in-tile ni,
   // row dy, column dx) relative to the tile origin: its pixel is gp0(tile) + uoff, its validity two or three compares,

@@ -789,7 +789,7 @@ struct Sched {
     else failed = true;        // a dropped wait would be a silent race between lanes: reported by the caller after the join
   }
   // ROCm 7.2: inside a stream capture, a stream that waits on an event DESCENDING from its
-  // own tail node crashes hipStreamEndCapture (tools/capture_patterns3.py "pp1"). The x_{i,j}
+  // own tail node crashes hipStreamEndCapture (regression test: tests/test_capture_gpu.py). The x_{i,j}
   // grid ping-pongs between levels all the time, so while capturing a lane with cross-lane
   // waits continues on a never-used stream that waits on the lane's tail event AND the
   // cross-lane events (no own tail -> plain fork semantics). Eager issue keeps fixed lanes.

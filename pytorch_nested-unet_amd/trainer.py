@@ -60,7 +60,7 @@ class TrainStep:
         # Data-parallel step layout (NUNET_DP_MODE). 1 (default): one lane-faithful graph for forward + loss + the whole
         # backward, ONE exchange of the complete gradient scratch, one graph for unpack + SGD. 0: backward cut in two phases
         # so that bucket 0's exchange runs beside phase 2. Measured on one MI355X (single-rank RCCL group,
-        # tools/dp_probe.py): the cut costs 500 us per step (phase 1 is the anti-diagonal's dependency chain with nothing
+        # NUNET_FORCE_DP=1 python bench.py): the cut costs 350-500 us per step (phase 1 is the anti-diagonal's dependency chain with nothing
         # beside it, 2.71 ms vs 2.18 ms) - more than the 36.7 MB exchange it hides is expected to take on >= 4 GPUs.
         # NUNET_DP_MODE unset / "auto": with more than one rank, capture() times layouts 1 and 2 on the real exchange and
         # keeps the faster (the decision is all-reduced, so every rank takes the same one); one rank: layout 1.
