@@ -8,7 +8,7 @@ IoU counts, backward, (gradient all-reduce for N>1), SGD — nothing skipped.
 Inputs are synthetic (pytorch_nested-unet_amd/synth.py) and resident in HBM before the
 timed region; each step copies the next staged batch into the graph's static inputs.
 
-  python bench.py --gpus 1 --steps 50 --warmup 10
+  python bench.py --gpus 1 --steps 200 --warmup 50
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,8 +35,8 @@ TRAIN_GFLOP_PER_IMG_96 = 29.081
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
