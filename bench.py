@@ -24,6 +24,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this image needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument otherwise);
+# the launcher environment normally carries it already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 

@@ -21,8 +21,10 @@ import os
 import time
 from collections import OrderedDict
 
-import torch
-import yaml
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this image
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
 
 import torch.distributed as dist
 
