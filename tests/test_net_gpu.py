@@ -380,6 +380,36 @@ def test_training_log_follows_reference(dtype, iou_band, synth):
     assert rows[-1, 0] < 0.5 * rows[0, 0]
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 5e-5), ("bf16", 1e-3)])
+def test_cfg1_bs8_96_training_follows_oracle(dtype, tol, synth):
+    """BASELINE.json configs[0] (batch 8, 96x96 - the reference's own CPU-runnable case, trains.py defaults: BCEDiceLoss,
+    SGD lr 1e-3 / momentum 0.9 / wd 1e-4) through the hipGraph TrainStep against the fp32 CPU oracle running the same
+    loop (reference trains.py:113-135,229-231): per-step loss over 12 steps from the reference's default initialisation."""
+    from nunet_amd.trainer import TrainStep
+    n, hw, steps = 8, 96, 12
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, False).state_dict().items()}
+    batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=4321 + k) for k in range(3)]
+    m = nunet_amd.archs.NestedUNet(1, 3, False, dtype=dtype)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    ts = TrainStep(m, (n, 3, hw, hw))
+    ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+    hip = []
+    for k in range(steps):
+        img, msk = batches[k % 3]
+        ts.reset_meters()
+        ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+        hip.append(ts.epoch_stats()[0])
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    net = O.OracleNet({k: v.numpy() for k, v in sd.items()}, 1, 3, False)
+    opt = O.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    ref = [O.train_step(net, opt, torch.from_numpy(batches[k % 3][0]), torch.from_numpy(batches[k % 3][1]))[0] for k in range(steps)]
+    print("hip", " ".join("%.5f" % v for v in hip)); print("ref", " ".join("%.5f" % v for v in ref))
+    assert np.all(np.isfinite(hip))
+    assert np.max(np.abs(np.array(hip) - np.array(ref))) < tol, (hip, ref)
+
+
 def test_cfg2_bf16_bs16_96_training_follows_oracle(synth):
     """BASELINE.json configs[1] itself (bf16 storage, batch 16, 96x96, BCEDiceLoss, SGD defaults) through the
     hipGraph TrainStep, against the fp32 CPU oracle running the same loop (reference trains.py:113-135,229-231):
