@@ -9,6 +9,7 @@ Inputs are synthetic (pytorch_nested-unet_amd/synth.py) and resident in HBM befo
 timed region; each step copies the next staged batch into the graph's static inputs.
 
   python bench.py --gpus 1 --steps 200 --warmup 50
+  python bench.py --gpus N ...          (no launcher: spawns one child process per GPU itself, before any GPU call)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -28,14 +29,17 @@ sys.path.insert(0, ROOT)
 # the launcher environment normally carries it already
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
-
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 TRAIN_GFLOP_PER_IMG_96 = 29.081
 
 
-def parse():
+def train_gflop_per_img(hw):
+    """fwd + dgrad + wgrad of the fully convolutional net: proportional to the pixel count (x7.111 at 256, x28.44 at 512)."""
+    return TRAIN_GFLOP_PER_IMG_96 * (hw / 96.0) ** 2
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -50,7 +54,66 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, 16) = the GPU box's CPU share")
-    return ap.parse_args()
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 leg (the reference's own arithmetic, reported beside the bf16 line)")
+    ap.add_argument("--fp32-steps", type=int, default=30)
+    ap.add_argument("--dist-dry-run", action="store_true",
+                    help="rendezvous only: every rank joins a gloo group on the CPU, all-reduces its rank and rank 0 prints the ranks it saw "
+                         "(exercises the launcher / self-spawn path without a GPU)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher: one child process per GPU, started BEFORE this process has made any
+    GPU call (it never makes one: a process that touched the GPU must not be replaced or forked into ranks). Children get
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* exactly as torch.distributed.run would set them; rank 0's stdout (the JSON
+    line) is this process's stdout. Returns the worst child exit code."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NUNET_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        try:
+            p.wait()
+        except KeyboardInterrupt:
+            for q in procs:
+                q.terminate()
+            raise
+        rc = rc or p.returncode
+    if rc:          # a rank died: do not leave its peers waiting in a collective
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+    return rc
+
+
+def dist_dry_run(rank, world):
+    """Rendezvous check on the CPU (gloo): what a SCALE run needs to work before any kernel runs."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.zeros(world, dtype=torch.int64)
+    t[rank] = 1
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dist_dry_run": True, "backend": "gloo", "n_gpus": world, "ranks_seen": int(t.sum()),
+                          "world_size": dist.get_world_size()}))
+    dist.destroy_process_group()
 
 
 def cpu_baseline(args, budget_s):
@@ -107,13 +170,20 @@ def kernel_source_hash():
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one (nothing in this process has touched the GPU, torch is not even imported yet)
+        sys.exit(self_launch(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.dist_dry_run:
+        return dist_dry_run(rank, world)
+    global torch
+    import torch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -128,37 +198,47 @@ def main():
     from nunet_amd.trainer import TrainStep
     synth = nunet_amd.synth
 
-    torch.manual_seed(0)                                # identical replicas on every rank
-    model = nunet_amd.archs.NestedUNet(args.num_classes, 3, args.deep_supervision, dtype=args.dtype).to(dev)
-    model.train()
     n, hw = args.batch, args.size
-    ts = TrainStep(model, (n, 3, hw, hw), lr=1e-3, momentum=0.9, weight_decay=1e-4,
-                   use_graph=not args.no_graph)
-    # pre-stage a small pool of synthetic batches in HBM (rank-distinct shards)
-    pool = []
-    for k in range(4):
-        img, msk = synth.synth_batch(n, hw, hw, 3, args.num_classes, seed=1234 + 100 * rank + k)
-        pool.append((torch.from_numpy(img).to(dev), torch.from_numpy(msk).to(dev)))
-    ts.capture(*pool[0])
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        ts.step(*pool[k % len(pool)])
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ts.step(*pool[k % len(pool)])
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed_run(dtype, steps, warmup):
+        """Build the replica at `dtype`, capture the step, W untimed + K timed steps between barrier + synchronize pairs."""
+        torch.manual_seed(0)                                # identical replicas on every rank
+        model = nunet_amd.archs.NestedUNet(args.num_classes, 3, args.deep_supervision, dtype=dtype).to(dev)
+        model.train()
+        ts = TrainStep(model, (n, 3, hw, hw), lr=1e-3, momentum=0.9, weight_decay=1e-4, use_graph=not args.no_graph)
+        # pre-stage a small pool of synthetic batches in HBM (rank-distinct shards)
+        pool = []
+        for k in range(4):
+            img, msk = synth.synth_batch(n, hw, hw, 3, args.num_classes, seed=1234 + 100 * rank + k)
+            pool.append((torch.from_numpy(img).to(dev), torch.from_numpy(msk).to(dev)))
+        ts.capture(*pool[0])
+        for k in range(warmup):
+            ts.step(*pool[k % len(pool)])
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ts.step(*pool[k % len(pool)])
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return ts, dt
+
+    ts, dt = timed_run(args.dtype, args.steps, args.warmup)
     loss, iou = ts.epoch_stats()
+    dp_info = None
+    if world > 1 or force_dp:
+        dp_info = {"backend": dist.get_backend(), "rccl_ranks_seen": dist.get_world_size(), "layout": ts.dp_mode,
+                   "layout_chosen_by": "measurement at capture (slowest rank decides)" if ts.dp_choice else "NUNET_DP_MODE / default",
+                   "layout_ms": {"after_pass": ts.dp_choice[0], "bucket0_beside_pass": ts.dp_choice[1]} if ts.dp_choice else None,
+                   "exchange_mb": ts._scratch.numel() * 4 / 1e6}
 
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt
@@ -222,10 +302,24 @@ def main():
                                 "us_per_step": e["ms"] * 1e3 / reps,
                                 "tflops": (e["flops"] / (e["ms"] * 1e-3) / 1e12) if e["ms"] > 0 else 0.0,
                                 "gbs": (e["bytes"] / (e["ms"] * 1e-3) / 1e9) if e["ms"] > 0 else 0.0} for e in prof]
-        if hw == 96:
-            step_tflops = TRAIN_GFLOP_PER_IMG_96 * n / 1e3 / (ms_per_step * 1e-3)
-            roofline["whole_step_tflops"] = step_tflops
-            roofline["whole_step_frac_of_mfma_peak"] = step_tflops / PEAK[args.dtype]
+        step_tflops = train_gflop_per_img(hw) * n / 1e3 / (ms_per_step * 1e-3)
+        roofline["whole_step_tflops"] = step_tflops
+        roofline["whole_step_frac_of_mfma_peak"] = step_tflops / PEAK[args.dtype]
+
+    # The same workload in the REFERENCE's own arithmetic (fp32 storage, exact-fp32 MFMA 32x32x2; reference
+    # finished/archs1.py:14-32 has no autocast anywhere, and north_star's 1e-4 parity bound is an fp32 bound): a second
+    # timed region after the headline one, its own replica and graph, >= 20 steps. Reported beside the line, never as `value`.
+    fp32 = None
+    if rank == 0 and world == 1 and not args.no_fp32 and args.dtype != "fp32":
+        del ts
+        torch.cuda.empty_cache()
+        k32 = max(20, args.fp32_steps)
+        _, dt32 = timed_run("fp32", k32, 5)
+        ms32 = dt32 / k32 * 1e3
+        tf32 = train_gflop_per_img(hw) * n / 1e3 / (ms32 * 1e-3)
+        fp32 = {"value": n * k32 / dt32, "unit": "images/sec", "ms_per_step": ms32, "steps": k32, "warmup": 5,
+                "whole_step_tflops": tf32, "frac_of_fp32_mfma_peak": tf32 / PEAK["fp32"],
+                "note": "same workload and step, fp32 storage and exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference's precision"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -245,7 +339,10 @@ def main():
                                       "+allreduce" if world > 1 else "", 2 if args.deep_supervision else 1),
                        "global_batch": world * n, "parallelism": "dp%d" % world, "hip_graph": not args.no_graph},
             "final_loss": loss, "final_iou": iou,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32": fp32,
+            # what a SCALE record needs to be checkable: the ranks the collective backend really joined, the step layout the
+            # data-parallel TrainStep chose and the timings it chose by (None with one rank: no exchange in the step)
+            "dp": dp_info,
         }
         print(json.dumps(out))
     if world > 1 or force_dp:

@@ -73,3 +73,43 @@ def test_grad_ready_order_and_ranges():
     first = sum(rng[k][1] for k in parallel.grad_ready_order(False)[1:6])
     m0 = nunet_amd.archs.NestedUNet(1, 3, False)
     assert abs(first / sum(p.numel() for p in m0.parameters()) - 0.756) < 0.005
+
+
+def _run_bench(args, env_extra=None, timeout=180):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+def test_bench_self_launches_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must spawn its own ranks (the driver's first
+    multi-GPU run may call it exactly like the 1-GPU line): the parent makes no GPU call, the children rendezvous on
+    127.0.0.1, rank 0 alone prints ONE JSON line. Exercised up to the process group (gloo, CPU) by --dist-dry-run."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--dist-dry-run"])
+    assert rc == 0, err
+    assert len(lines) == 1
+    assert lines[0]["ranks_seen"] == 2 and lines[0]["world_size"] == 2 and lines[0]["n_gpus"] == 2
+
+
+def test_bench_under_a_launcher_keeps_its_environment():
+    """The documented launch (torch.distributed.run sets RANK / WORLD_SIZE): no second level of spawning."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--dist-dry-run"],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and '"ranks_seen": 2' in lines[0]
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    rc, lines, err = _run_bench(["--gpus", "2", "--dist-dry-run"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert rc != 0 and not lines and "does not match" in err
