@@ -125,6 +125,7 @@ typedef struct {
   int64_t slab_stride;              /* floats between slabs (0: 9*Cout*Cin) */
   int32_t max_slabs;                /* capacity of the caller's slab buffer (0: unlimited, i.e. nunet_conv3x3_wgrad_slabs of it) */
   int32_t target_wgs;               /* workgroups the launch should reach through the K-split (0: 256) */
+  int64_t dw_floats;                /* capacity of `dw` in floats: the launch is refused (NUNET_EINVAL) unless every slab it would write fits */
 } nunet_wgrad_desc;
 
 /* Partial weight gradients: the contraction over pixels is split into nunet_conv3x3_wgrad_slabs(d) slices; slice s
@@ -224,7 +225,7 @@ int nunet_head_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, in
 int nunet_head_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K,
                    const void* x, int32_t PX, const float* w, const float* dlogits,
                    void* dx, int32_t PDX, int32_t accumulate,
-                   float* dw_slabs, int32_t nslabs, nunet_stream_t s);
+                   float* dw_slabs, int32_t nslabs, nunet_stream_t s);   /* dw_slabs: nslabs * (K*C + K) floats */
 int nunet_head_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t K,
                        const void* x, int32_t PX, const float* w, const float* dlogits,
                        void* dx, int32_t PDX, int32_t accumulate,
@@ -233,32 +234,41 @@ int nunet_head_bwd_bnr(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C
 /* ------------------------------------------------------------------------ */
 /* BCEDiceLoss (losses.py:103-117), iou_score (metrics.py:6-18)              */
 /* ------------------------------------------------------------------------ */
-/* ws: [N][3] (sum p*t, sum p, sum t) + [1] (sum bce) + per-block partial slabs (summed in fixed order). loss: [1]. */
+/* Every entry that takes a caller-provided workspace (or the plan arena) also takes its size in bytes and returns
+ * NUNET_EINVAL when it is smaller than the matching *_bytes() query says: the library never writes past what the
+ * caller said it owns (a layout change on one side of the ABI used to surface as a GPU memory fault).
+ * ws: [N][3] (sum p*t, sum p, sum t) + [1] (sum bce) + per-block partial slabs (summed in fixed order). loss: [1]. */
 size_t nunet_bce_dice_ws_bytes(int32_t N);
 int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int64_t per_sample,
-                       float* ws, float* loss, nunet_stream_t s);
+                       float* ws, size_t ws_bytes, float* loss, nunet_stream_t s);
 /* dlogits = gscale[0] * dloss/dlogits */
 int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per_sample,
-                       const float* ws, const float* gscale, float* dlogits, nunet_stream_t s);
+                       const float* ws, size_t ws_bytes, const float* gscale, float* dlogits, nunet_stream_t s);
 /* Fused loss step of the training loop (trains.py:118-128,135-136): BCEDice of every head,
  * dlogits of their mean, IoU counts of the last head. logits/dlogits: [heads][N][per].
  * loss_out: [heads+1] (per head, then the mean). meters (may be NULL): double[4]:
- * [0] += mean loss, [1] += IoU of this batch, [2],[3] = intersection / union counts. */
-size_t nunet_loss_step_ws_bytes(int32_t N, int32_t heads);
+ * [0] += mean loss, [1] += IoU of this batch, [2],[3] = intersection / union counts.
+ * loss_kind: NUNET_LOSS_BCE_DICE (losses.py:103-117) or NUNET_LOSS_LOVASZ_HINGE (losses.py:120-129, the loss behind the
+ * reference's published table README.md:102-108; one class only: the reference squeezes dim 1). */
+enum { NUNET_LOSS_BCE_DICE = 0, NUNET_LOSS_LOVASZ_HINGE = 1 };
+size_t nunet_loss_step_ws_bytes(int32_t N, int64_t per_sample, int32_t heads, int32_t loss_kind);
 int nunet_loss_step(const float* logits, const float* target, int32_t N, int64_t per_sample,
-                    int32_t heads, float* ws, float* dlogits, float* loss_out, double* meters,
-                    nunet_stream_t s);
+                    int32_t heads, int32_t loss_kind, float* ws, size_t ws_bytes, float* dlogits, float* loss_out,
+                    double* meters, float iou_logit_threshold, nunet_stream_t s);
 /* LovaszHingeLoss (losses.py:49-96,120-129; per_image=True, mean over images). logits/target: [N][per_image]
  * (num_classes must be 1: the reference squeezes dim 1). Per-image sort: in LDS up to 16384 pixels, chunk sorts +
  * global bitonic merge passes above (up to 2^22); ws of nunet_lovasz_ws_bytes(N, per_image) bytes, 256-byte aligned.
  * dlogits_unit receives d loss / d logits for an upstream gradient of 1; _bwd scales it by gscale[0]. */
 size_t nunet_lovasz_ws_bytes(int32_t N, int64_t per_image);
 int nunet_lovasz_hinge_fwd(const float* logits, const float* target, int32_t N, int64_t per_image,
-                           float* ws, float* dlogits_unit, float* loss, nunet_stream_t s);
+                           float* ws, size_t ws_bytes, float* dlogits_unit, float* loss, nunet_stream_t s);
 int nunet_lovasz_hinge_bwd(const float* dlogits_unit, const float* gscale, int64_t n, float* dlogits,
                            nunet_stream_t s);
-/* counts[0] += |A&B|, counts[1] += |A|B|, A = logits>0, B = target>0.5 */
-int nunet_iou_counts(const float* logits, const float* target, int64_t n,
+/* counts[0] += |A&B|, counts[1] += |A|B|, A = logits >= logit_threshold, B = target > 0.5.
+ * logit_threshold = the smallest fp32 logit x for which the REFERENCE's `torch.sigmoid(x) > 0.5` holds in fp32
+ * (metrics.py:10-12; it is a few 1e-8 above zero, sigmoid(x) rounds to exactly 0.5 below it): integer counts stay
+ * bit-exact against the reference. The caller finds it by bisection with the reference's sigmoid. */
+int nunet_iou_counts(const float* logits, const float* target, int64_t n, float logit_threshold,
                      unsigned long long* counts, nunet_stream_t s);
 /* Mask export of the evaluation driver (reference val.py:100-105): out[i] = uint8(sigmoid(logits[i]) * 255), bit-exact
  * against the reference's sigmoid: thresholds[k-1] (k = 1..255, fp32, device) = the smallest logit whose byte is >= k as
@@ -313,13 +323,21 @@ int32_t nunet_plan_num_heads(const nunet_plan* p);
  * bnbuf:  flat fp32 [running_mean, running_var] per BN in state_dict order.
  * nbt:    int64 per BN layer.
  * input:  NCHW fp32. logits: [heads][N][K][H][W] fp32.
+ * arena / arena_bytes: the caller's buffer of at least nunet_plan_arena_bytes(p) bytes (NUNET_EINVAL when smaller), 256-byte aligned.
  * training: bit 0 = training mode (batch statistics, running-stat update); bit 1 = the packed weights in `arena`
- * are current (left so by nunet_plan_update / nunet_plan_repack on these parameters): skip the repack. */
+ * are current (left so by nunet_plan_update / nunet_plan_repack on these parameters): skip the repack; bit 2 = the image
+ * was staged into the arena by nunet_plan_stage_u8 (`input` is ignored and may be NULL). */
 int nunet_plan_forward(nunet_plan* p, const float* params, float* bnbuf, int64_t* nbt,
-                       const float* input, void* arena, float* logits, int32_t training,
+                       const float* input, void* arena, size_t arena_bytes, float* logits, int32_t training,
                        nunet_stream_t s);
+/* Device-side input pipeline into the plan (reference dataset.py:66-74, trains.py:258-259,266): a uint8 NHWC batch
+ * [N][H][W][input_channels] -> ((u/255 - mean[c]) / std[c]) * post_scale in the storage dtype, written as the padded NHWC
+ * image the first conv reads (same arithmetic and rounding as nunet_preprocess_u8 + the layout step of
+ * nunet_plan_forward, which bit 2 of `training` then skips). aug: as nunet_preprocess_u8 (NULL = none). */
+int nunet_plan_stage_u8(nunet_plan* p, const uint8_t* u8_nhwc, const float* mean, const float* stdv, const int32_t* aug,
+                        float post_scale, void* arena, size_t arena_bytes, nunet_stream_t s);
 /* grads: flat fp32 in params order. accumulate: += instead of assign. */
-int nunet_plan_backward(nunet_plan* p, const float* params, const float* dlogits, void* arena,
+int nunet_plan_backward(nunet_plan* p, const float* params, const float* dlogits, void* arena, size_t arena_bytes,
                         float* grads, int32_t accumulate, nunet_stream_t s);
 /* Backward in phases, for overlapping the data-parallel gradient exchange with the rest of backward:
  * phases bit 0 = clear scratch + heads + the last anti-diagonal's blocks (75 % of the gradient bytes),
@@ -327,7 +345,7 @@ int nunet_plan_backward(nunet_plan* p, const float* params, const float* dlogits
  * The native-layout fp32 gradient scratch lives in the arena at *byte_offset, in gradient-ready order:
  * its first *bucket0_floats floats are final after phase 1, all *total_floats after phase 2; a
  * data-parallel caller all-reduces those two ranges (sum) and then runs phase 4. */
-int nunet_plan_backward_phase(nunet_plan* p, const float* params, const float* dlogits, void* arena,
+int nunet_plan_backward_phase(nunet_plan* p, const float* params, const float* dlogits, void* arena, size_t arena_bytes,
                               float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s);
 int nunet_plan_grad_scratch(const nunet_plan* p, int64_t* byte_offset, int64_t* bucket0_floats,
                             int64_t* total_floats);
@@ -344,22 +362,20 @@ int nunet_plan_bucket0_wait(nunet_plan* p, nunet_stream_t s);
  * (reference trains.py:229-231; lr from device memory, momentum buffer `momentum`, weight decay, nesterov,
  * grad_scale = 1/world) on the fp32 master parameters -> both packed weight layouts. `grads` (flat OIHW, may be NULL)
  * receives the scaled gradients. */
-int nunet_plan_update(nunet_plan* p, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
+int nunet_plan_update(nunet_plan* p, float* params, float* momentum, void* arena, size_t arena_bytes, const float* lr_dev, float mom, float wd,
                       int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s);
 /* The same optimiser step without the repack (the next nunet_plan_forward repacks as usual): gradient scratch -> SGD,
  * one launch instead of unpack + nunet_sgd_step, no OIHW gradient round trip unless `grads` is given. */
-int nunet_plan_sgd(nunet_plan* p, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
+int nunet_plan_sgd(nunet_plan* p, float* params, float* momentum, void* arena, size_t arena_bytes, const float* lr_dev, float mom, float wd,
                    int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s);
 /* Repack the weight layouts from the fp32 parameters (what nunet_plan_forward does first unless told they are current). */
-int nunet_plan_repack(nunet_plan* p, const float* params, void* arena, nunet_stream_t s);
+int nunet_plan_repack(nunet_plan* p, const float* params, void* arena, size_t arena_bytes, nunet_stream_t s);
 /* Multi-lane issue (default on; env NUNET_MULTISTREAM=0 disables): the plan forks onto
  * its own streams (one per pyramid level + one per level for weight gradients), with event
  * dependencies per buffer, and re-joins `s` before returning control - all work is ordered
  * before anything the caller enqueues on `s` afterwards, and a capture of `s` records the
  * lanes as parallel branches of the same hipGraph. */
 int nunet_plan_set_multistream(nunet_plan* p, int32_t enable);
-/* use caller-owned streams as lanes (n >= 1, cycled over the 10 lanes) instead of the plan's own */
-int nunet_plan_set_lanes(nunet_plan* p, nunet_stream_t* lanes, int32_t n);
 /* debug/test access to an intermediate: name like "x0_0", "x2_1" (block
  * outputs, NHWC). Returns byte offset into arena; fills pitch/channels. */
 int64_t nunet_plan_feature(const nunet_plan* p, int32_t i, int32_t j, int32_t* pitch,
@@ -391,14 +407,6 @@ int nunet_graph_end(nunet_stream_t stream, nunet_graph** out);
 int nunet_graph_launch(nunet_graph* graph, nunet_stream_t stream);
 int nunet_graph_info(const nunet_graph* graph, int32_t* nodes, int32_t* edges_captured, int32_t* edges_final, int32_t* padding, int32_t* lanes);
 void nunet_graph_destroy(nunet_graph* graph);
-
-/* Diagnostic: with NUNET_STAMPS=1 in the environment every op the plan schedules is followed by a
- * 1-thread kernel that stores the 100 MHz wall clock; this reads them back (synchronises) for the
- * last forward (pass 0) / backward (pass 1), labels one per line ("L<lane> B<i><j>.<op>").
- * Works inside hipGraph replays, where a profiler's dispatch overhead would distort the timeline. */
-int nunet_plan_stamps_read(nunet_plan* plan, int32_t pass, uint64_t* ticks, int32_t cap, int32_t* n_out, char* labels, int32_t label_bytes);
-/* Diagnostic (tools/graph_sched_probe.py): `tag` workgroups, the first spins `us` microseconds. */
-int nunet_debug_spin(int32_t us, int32_t tag, nunet_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -178,19 +178,16 @@ def bce_dice_loss_np(logits, target):
 
 def iou_score(logits, target):
     """metrics.py:6-18: global (whole-batch) IoU of sigmoid(x)>0.5 vs t>0.5."""
-    x = logits.detach().cpu().numpy() if torch.is_tensor(logits) else np.asarray(logits)
-    t = target.detach().cpu().numpy() if torch.is_tensor(target) else np.asarray(target)
-    o_ = (1.0 / (1.0 + np.exp(-x.astype(np.float64)))) > 0.5
-    t_ = t > 0.5
-    inter = (o_ & t_).sum()
-    union = (o_ | t_).sum()
+    inter, union = iou_counts(logits, target)
     return (inter + 1e-5) / (union + 1e-5)
 
 
 def iou_counts(logits, target):
-    x = np.asarray(logits)
-    t = np.asarray(target)
-    o_ = x > 0
+    """The reference's own expression, in its own precision: `torch.sigmoid(output)` on the fp32 tensor, then `> 0.5`
+    on the host (metrics.py:10-12). NOT `x > 0`: in fp32 the sigmoid of a logit in (0, ~9e-8) rounds to exactly 0.5."""
+    x = logits.detach().cpu() if torch.is_tensor(logits) else torch.from_numpy(np.asarray(logits))
+    t = target.detach().cpu().numpy() if torch.is_tensor(target) else np.asarray(target)
+    o_ = torch.sigmoid(x.float()).numpy() > 0.5
     t_ = t > 0.5
     return int((o_ & t_).sum()), int((o_ | t_).sum())
 

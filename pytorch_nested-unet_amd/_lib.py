@@ -18,7 +18,7 @@ DTYPES = {"fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F
           torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
-_vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+_vp, _i32, _i64, _u32, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_size_t
 BN_SUM_REPLICAS = 8        # NUNET_BN_SUM_REPLICAS in include/nunet.h
 FX_WORDS = 2               # NUNET_FX_WORDS: int64 words of one fixed-point accumulator (hi * 2^-20 + lo * 2^-60)
 TF_NONE, TF_BN_RELU, TF_BN_RELU_BWD = 0, 1, 2
@@ -68,7 +68,7 @@ class WgradDesc(C.Structure):
                 ("src0", _vp), ("C0", _i32), ("P0", _i32),
                 ("src1", _vp), ("C1", _i32), ("P1", _i32),
                 ("dy", _vp), ("Cout", _i32), ("PY", _i32),
-                ("dw", _vp), ("slab_stride", _i64), ("max_slabs", _i32), ("target_wgs", _i32)]
+                ("dw", _vp), ("slab_stride", _i64), ("max_slabs", _i32), ("target_wgs", _i32), ("dw_floats", _i64)]
 
 
 class BnFwdDesc(C.Structure):
@@ -126,14 +126,14 @@ _SIG = {
     "nunet_head_bwd": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "nunet_head_bwd_bnr": (_i32, [_i32] * 6 + [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, C.POINTER(BnrDesc), _vp]),
     "nunet_bce_dice_ws_bytes": (C.c_size_t, [_i32]),
-    "nunet_bce_dice_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
-    "nunet_bce_dice_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
-    "nunet_loss_step_ws_bytes": (C.c_size_t, [_i32, _i32]),
-    "nunet_loss_step": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "nunet_bce_dice_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _sz, _vp, _vp]),
+    "nunet_bce_dice_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _sz, _vp, _vp, _vp]),
+    "nunet_loss_step_ws_bytes": (C.c_size_t, [_i32, _i64, _i32, _i32]),
+    "nunet_loss_step": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _sz, _vp, _vp, _vp, _f32, _vp]),
     "nunet_lovasz_ws_bytes": (C.c_size_t, [_i32, _i64]),
-    "nunet_lovasz_hinge_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "nunet_lovasz_hinge_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _sz, _vp, _vp, _vp]),
     "nunet_lovasz_hinge_bwd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "nunet_iou_counts": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "nunet_iou_counts": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp]),
     "nunet_sigmoid_u8": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "nunet_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _i32, _f32, _vp]),
     "nunet_preprocess_u8": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
@@ -145,15 +145,16 @@ _SIG = {
     "nunet_plan_bnbuf_count": (_i64, [_vp]),
     "nunet_plan_bn_layers": (_i32, [_vp]),
     "nunet_plan_num_heads": (_i32, [_vp]),
-    "nunet_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "nunet_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "nunet_plan_backward_phase": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "nunet_plan_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i32, _vp]),
+    "nunet_plan_stage_u8": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
+    "nunet_plan_backward": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp, _i32, _vp]),
+    "nunet_plan_backward_phase": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp, _i32, _i32, _vp]),
     "nunet_plan_grad_scratch": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "nunet_plan_bucket0_enable": (_i32, [_vp, _i32]),
     "nunet_plan_bucket0_wait": (_i32, [_vp, _vp]),
-    "nunet_plan_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
-    "nunet_plan_repack": (_i32, [_vp, _vp, _vp, _vp]),
-    "nunet_plan_sgd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
+    "nunet_plan_update": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
+    "nunet_plan_repack": (_i32, [_vp, _vp, _vp, _sz, _vp]),
+    "nunet_plan_sgd": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
     "nunet_plan_feature": (_i64, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "nunet_plan_set_multistream": (_i32, [_vp, _i32]),
     "nunet_plan_set_lanes": (_i32, [_vp, C.POINTER(_vp), _i32]),
@@ -222,6 +223,14 @@ def check(rc, what=""):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+LOSS_BCE_DICE, LOSS_LOVASZ_HINGE = 0, 1
+
+
+def nbytes(t):
+    """size in bytes a tensor hands to the library next to its pointer (every workspace / arena argument has one)"""
+    return 0 if t is None else t.numel() * t.element_size()
 
 
 def ptr(t, byte_offset=0):

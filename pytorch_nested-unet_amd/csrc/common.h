@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "../../include/nunet.h"
+#include "../../include/nunet_diag.h"
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;

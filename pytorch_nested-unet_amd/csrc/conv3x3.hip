@@ -1347,6 +1347,12 @@ static int wgrad_check(const nunet_wgrad_desc* d) {
   }
   NUNET_REQUIRE(d->slab_stride == 0 || d->slab_stride >= 9LL * d->Cout * (d->C0 + d->C1), "wgrad: slab_stride smaller than one slab");
   NUNET_REQUIRE(d->max_slabs >= 0 && d->target_wgs >= 0, "wgrad: max_slabs / target_wgs");
+  {
+    // every slab the launch will write must fit what the caller says `dw` holds
+    const long long stride = d->slab_stride > 0 ? d->slab_stride : 9LL * d->Cout * (d->C0 + d->C1);
+    const long long need = (long long)(nunet_conv3x3_wgrad_slabs(d) - 1) * stride + 9LL * d->Cout * (d->C0 + d->C1);
+    NUNET_REQUIRE(d->dw_floats >= need, "wgrad: dw holds %lld floats, the %d slabs of this launch need %lld", (long long)d->dw_floats, (int)nunet_conv3x3_wgrad_slabs(d), need);
+  }
   return NUNET_OK;
 }
 extern "C" int nunet_conv3x3_wgrad(const nunet_wgrad_desc* d, nunet_stream_t s) {

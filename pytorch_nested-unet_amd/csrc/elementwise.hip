@@ -974,8 +974,9 @@ __global__ __launch_bounds__(256) void bce_dice_bwd_kernel(const float* __restri
   }
 }
 extern "C" size_t nunet_bce_dice_ws_bytes(int32_t N) { return (size_t)(3 * N + 1 + (size_t)N * BCE_GX * 4) * sizeof(float); }
-extern "C" int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int64_t per, float* ws, float* loss, nunet_stream_t s) {
+extern "C" int nunet_bce_dice_fwd(const float* logits, const float* target, int32_t N, int64_t per, float* ws, size_t ws_bytes, float* loss, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && loss && N > 0 && per > 0, "bce_dice_fwd: bad args");
+  NUNET_REQUIRE(ws_bytes >= nunet_bce_dice_ws_bytes(N), "bce_dice_fwd: workspace of %zu bytes, nunet_bce_dice_ws_bytes(%d) = %zu", ws_bytes, (int)N, nunet_bce_dice_ws_bytes(N));
   hipStream_t st = (hipStream_t)s;
   const int gx = grid_for(per, 256 * 4, BCE_GX);
   ProfScope ps(PC_LOSS, 0, (double)N * per * 8, st);
@@ -983,8 +984,9 @@ extern "C" int nunet_bce_dice_fwd(const float* logits, const float* target, int3
   NUNET_LAUNCH(bce_dice_final_kernel, dim3(1), dim3(64), 0, st, ws, N, gx, per, loss);
   return nunet_check_launch("bce_dice_fwd");
 }
-extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per, const float* ws, const float* gscale, float* dlogits, nunet_stream_t s) {
+extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int32_t N, int64_t per, const float* ws, size_t ws_bytes, const float* gscale, float* dlogits, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && dlogits && N > 0 && per > 0, "bce_dice_bwd: bad args");
+  NUNET_REQUIRE(ws_bytes >= nunet_bce_dice_ws_bytes(N), "bce_dice_bwd: workspace of %zu bytes, nunet_bce_dice_ws_bytes(%d) = %zu", ws_bytes, (int)N, nunet_bce_dice_ws_bytes(N));
   const int gx = grid_for(per, 256 * 4, 64);
   ProfScope ps(PC_LOSS, 0, (double)N * per * 12, (hipStream_t)s);
   NUNET_LAUNCH(bce_dice_bwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)s, logits, target, per, ws, gscale, dlogits, N);
@@ -1000,7 +1002,7 @@ extern "C" int nunet_bce_dice_bwd(const float* logits, const float* target, int3
 // zero launch ahead, no same-address atomics, and bit-reproducible run to run); the second kernel adds the <= 64 slabs
 // of its image with one wave.
 constexpr int LOSS_GX = 64;     // most blocks per (image, head)
-__global__ __launch_bounds__(256) void loss_step_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, float* __restrict__ ws, int N, int heads) {
+__global__ __launch_bounds__(256) void loss_step_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t per, float* __restrict__ ws, int N, int heads, float iou_thr) {
   const int n = blockIdx.y, hd = blockIdx.z;
   const float* xs = x + ((int64_t)hd * N + n) * per;
   const float* ts = t + (int64_t)n * per;
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(256) void loss_step_partial_kernel(const float* __r
     const float pv = sigmoidf_(xv);
     a0 += pv * tv; a1 += pv; a2 += tv;
     a3 += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
-    const bool a = xv > 0.f, b = tv > 0.5f; ci += (a && b) ? 1u : 0u; cu += (a || b) ? 1u : 0u;
+    const bool a = xv >= iou_thr, b = tv > 0.5f; ci += (a && b) ? 1u : 0u; cu += (a || b) ? 1u : 0u;
   }
   a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
 #pragma unroll
@@ -1100,27 +1102,39 @@ __global__ __launch_bounds__(256) void loss_step_bwd_kernel(const float* __restr
     ds[i] = g * (kb * (pv - tv) - invN * ddice);
   }
 }
-extern "C" size_t nunet_loss_step_ws_bytes(int32_t N, int32_t heads) {
+size_t lovasz_step_ws_bytes(int32_t N, int64_t per, int32_t heads);    // lovasz.hip
+int lovasz_loss_step(const float* logits, const float* target, int32_t N, int64_t per, int32_t heads, float* ws, float* dlogits,
+                     float* loss_out, double* meters, float iou_thr, hipStream_t st);
+extern "C" size_t nunet_loss_step_ws_bytes(int32_t N, int64_t per, int32_t heads, int32_t loss_kind) {
+  if (N <= 0 || per <= 0 || heads < 1) return 0;
+  if (loss_kind == NUNET_LOSS_LOVASZ_HINGE) return lovasz_step_ws_bytes(N, per, heads);
   return (size_t)heads * N * LOSS_GX * 6 * sizeof(float);
 }
-extern "C" int nunet_loss_step(const float* logits, const float* target, int32_t N, int64_t per, int32_t heads, float* ws, float* dlogits, float* loss_out, double* meters, nunet_stream_t s) {
+extern "C" int nunet_loss_step(const float* logits, const float* target, int32_t N, int64_t per, int32_t heads, int32_t loss_kind, float* ws, size_t ws_bytes,
+                               float* dlogits, float* loss_out, double* meters, float iou_logit_threshold, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && dlogits && loss_out && N > 0 && per > 0 && heads >= 1 && heads <= 8, "loss_step: bad args");
+  NUNET_REQUIRE(loss_kind == NUNET_LOSS_BCE_DICE || loss_kind == NUNET_LOSS_LOVASZ_HINGE, "loss_step: loss_kind %d", (int)loss_kind);
   NUNET_REQUIRE(per <= (1ll << 24), "loss_step: image too large");    // per-image IoU counts stay exact in fp32
+  NUNET_REQUIRE(ws_bytes >= nunet_loss_step_ws_bytes(N, per, heads, loss_kind), "loss_step: workspace of %zu bytes, nunet_loss_step_ws_bytes = %zu",
+                ws_bytes, nunet_loss_step_ws_bytes(N, per, heads, loss_kind));
   hipStream_t st = (hipStream_t)s;
+  if (loss_kind == NUNET_LOSS_LOVASZ_HINGE) return lovasz_loss_step(logits, target, N, per, heads, ws, dlogits, loss_out, meters, iou_logit_threshold, st);
   const int gx = grid_for(per, 256, LOSS_GX);     // one element per thread up to 128x128 images: the step waits on this pair of launches
   ProfScope ps(PC_LOSS, 0, (double)N * per * heads * 16, st);
-  NUNET_LAUNCH(loss_step_partial_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, N, heads);
+  NUNET_LAUNCH(loss_step_partial_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, N, heads, iou_logit_threshold);
   NUNET_LAUNCH(loss_step_bwd_kernel, dim3(gx, N, heads), dim3(256), 0, st, logits, target, per, ws, gx, N, heads, dlogits, loss_out, meters);
   return nunet_check_launch("loss_step");
 }
 
 // ---------------------------------------------------------------------------
-// iou_score counts (metrics.py:10-14): sigmoid(x) > 0.5  <=>  x > 0
+// iou_score counts (metrics.py:10-14): sigmoid(x) > 0.5  <=>  x >= thr, with thr the smallest fp32 logit whose
+// REFERENCE sigmoid (fp32, rounded) exceeds 0.5 - not x > 0: in fp32, sigmoid(x) == 0.5 exactly for 0 < x <~ 6e-8.
+// The caller derives thr from the reference's own sigmoid by bisection (metrics.iou_logit_threshold). NaN -> false.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n, unsigned long long* __restrict__ counts) {
+__global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n, float thr, unsigned long long* __restrict__ counts) {
   unsigned int ci = 0, cu = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const bool a = x[i] > 0.f, b = t[i] > 0.5f;
+    const bool a = x[i] >= thr, b = t[i] > 0.5f;
     ci += (a && b) ? 1u : 0u;
     cu += (a || b) ? 1u : 0u;
   }
@@ -1131,10 +1145,10 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict
     atomicAdd(&counts[1], (unsigned long long)cu);
   }
 }
-extern "C" int nunet_iou_counts(const float* logits, const float* target, int64_t n, unsigned long long* counts, nunet_stream_t s) {
+extern "C" int nunet_iou_counts(const float* logits, const float* target, int64_t n, float logit_threshold, unsigned long long* counts, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && counts && n > 0, "iou_counts: bad args");
   ProfScope ps(PC_LOSS, 0, (double)n * 8, (hipStream_t)s);
-  NUNET_LAUNCH(iou_counts_kernel, dim3(grid_for(n, 256 * 4, 256)), dim3(256), 0, (hipStream_t)s, logits, target, n, counts);
+  NUNET_LAUNCH(iou_counts_kernel, dim3(grid_for(n, 256 * 4, 256)), dim3(256), 0, (hipStream_t)s, logits, target, n, logit_threshold, counts);
   return nunet_check_launch("iou_counts");
 }
 

@@ -266,9 +266,11 @@ extern "C" size_t nunet_lovasz_ws_bytes(int32_t N, int64_t per_image) {
 
 // loss = mean over images of the Lovasz hinge; dlogits_unit = d loss / d logits (for an upstream gradient of 1)
 extern "C" int nunet_lovasz_hinge_fwd(const float* logits, const float* target, int32_t N, int64_t per_image,
-                                      float* ws, float* dlogits_unit, float* loss, nunet_stream_t s) {
+                                      float* ws, size_t ws_bytes, float* dlogits_unit, float* loss, nunet_stream_t s) {
   NUNET_REQUIRE(logits && target && ws && dlogits_unit && loss && N > 0 && per_image > 0, "lovasz_hinge_fwd: bad args");
   NUNET_REQUIRE(per_image <= (1LL << 22), "lovasz_hinge_fwd: %lld pixels per image exceed the limit of 2^22", (long long)per_image);
+  NUNET_REQUIRE(ws_bytes >= nunet_lovasz_ws_bytes(N, per_image), "lovasz_hinge_fwd: workspace of %zu bytes, nunet_lovasz_ws_bytes = %zu", ws_bytes, nunet_lovasz_ws_bytes(N, per_image));
+  NUNET_REQUIRE(((uintptr_t)ws & 7) == 0, "lovasz_hinge_fwd: workspace must be 8-byte aligned");
   hipStream_t st = (hipStream_t)s;
   static bool attr_set = false;
   if (!attr_set) {
@@ -308,4 +310,56 @@ extern "C" int nunet_lovasz_hinge_bwd(const float* dlogits_unit, const float* gs
   if (g > 2048) g = 2048;
   NUNET_LAUNCH(scale_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, dlogits_unit, gscale, dlogits, n);
   return nunet_check_launch("lovasz_hinge_bwd");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// LovaszHingeLoss inside the fused training step (nunet_loss_step with NUNET_LOSS_LOVASZ_HINGE): the loss of every
+// head (reference trains.py:118-123: their mean under deep supervision), d mean / d logits, the IoU counts of the
+// last head (trains.py:124,128) and the epoch meters - the same outputs as the BCEDice form, so the step's graph
+// does not care which loss it carries. Workspace: per head one nunet_lovasz_ws_bytes() region, then uint64[2] counts.
+// ---------------------------------------------------------------------------------------------------------
+static size_t lovasz_head_ws(int32_t N, int64_t per) { return (nunet_lovasz_ws_bytes(N, per) + 255) / 256 * 256; }
+size_t lovasz_step_ws_bytes(int32_t N, int64_t per, int32_t heads) { return (size_t)heads * lovasz_head_ws(N, per) + 256; }
+
+// dlogits (unit gradients of every head) *= 1 / heads; IoU counts of the last head (integer atomics: order-independent)
+__global__ __launch_bounds__(256) void lovasz_step_scale_kernel(float* __restrict__ dx, const float* __restrict__ x_last, const float* __restrict__ t,
+                                                                int64_t n_all, int64_t n_img, float inv_heads, float thr, unsigned long long* __restrict__ cnt) {
+  unsigned ci = 0, cu = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
+    dx[i] *= inv_heads;
+    if (i < n_img) { const bool a = x_last[i] >= thr, b = t[i] > 0.5f; ci += (a && b) ? 1u : 0u; cu += (a || b) ? 1u : 0u; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o); cu += __shfl_xor(cu, o); }
+  if ((threadIdx.x & 63) == 0 && (ci | cu)) { atomicAdd(&cnt[0], (unsigned long long)ci); atomicAdd(&cnt[1], (unsigned long long)cu); }
+}
+__global__ void lovasz_step_final_kernel(float* __restrict__ loss_out, int heads, const unsigned long long* __restrict__ cnt, double* __restrict__ meters) {
+  float mean = 0.f;
+  for (int k = 0; k < heads; ++k) mean += loss_out[k];
+  mean /= (float)heads;
+  loss_out[heads] = mean;
+  if (meters) {
+    const double inter = (double)cnt[0], uni = (double)cnt[1];
+    meters[0] += (double)mean;
+    meters[1] += (inter + 1e-5) / (uni + 1e-5);
+    meters[2] = inter; meters[3] = uni;
+  }
+}
+int lovasz_loss_step(const float* logits, const float* target, int32_t N, int64_t per, int32_t heads, float* ws, float* dlogits,
+                     float* loss_out, double* meters, float iou_thr, hipStream_t st) {
+  const size_t hw = lovasz_head_ws(N, per);
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>((char*)ws + (size_t)heads * hw);
+  int rc = nunet_zero_async(cnt, 16, st);
+  for (int k = 0; k < heads && rc == NUNET_OK; ++k)
+    rc = nunet_lovasz_hinge_fwd(logits + (size_t)k * N * per, target, N, per, reinterpret_cast<float*>((char*)ws + (size_t)k * hw), hw,
+                                dlogits + (size_t)k * N * per, loss_out + k, (nunet_stream_t)st);
+  if (rc) return rc;
+  const int64_t n_img = (int64_t)N * per, n_all = n_img * heads;
+  int64_t g = (n_all + 1023) / 1024;
+  if (g > 1024) g = 1024;
+  NUNET_LAUNCH(lovasz_step_scale_kernel, dim3((unsigned)g), dim3(256), 0, st, dlogits, logits + (size_t)(heads - 1) * N * per, target, n_all, n_img,
+               1.f / (float)heads, iou_thr, cnt);
+  NUNET_LAUNCH(lovasz_step_final_kernel, dim3(1), dim3(1), 0, st, loss_out, (int)heads, cnt, meters);
+  return nunet_check_launch("loss_step (lovasz hinge)");
 }

@@ -961,9 +961,16 @@ static int blk_index(const nunet_plan* P, int i, int in_prefix_zero_only) {
   return -1;
 }
 
-extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnbuf, int64_t* nbt, const float* input, void* arena, float* logits, int32_t training_flags, nunet_stream_t s) {
+// every plan entry that touches the arena checks what the caller says it owns against the plan's own layout
+#define ARENA_CHECK(what) \
+  NUNET_REQUIRE(arena_bytes >= P->total, what ": arena of %zu bytes, nunet_plan_arena_bytes() = %zu", (size_t)arena_bytes, P->total); \
+  NUNET_REQUIRE(((uintptr_t)arena & 255) == 0, what ": arena must be 256-byte aligned")
+
+extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnbuf, int64_t* nbt, const float* input, void* arena, size_t arena_bytes, float* logits, int32_t training_flags, nunet_stream_t s) {
   const int32_t training = training_flags & 1;
-  NUNET_REQUIRE(P && params && input && arena && logits, "plan_forward: null pointer");
+  const bool staged = (training_flags & 4) != 0;       // the image already sits in the arena (nunet_plan_stage_u8): no layout launch
+  NUNET_REQUIRE(P && params && (input || staged) && arena && logits, "plan_forward: null pointer");
+  ARENA_CHECK("plan_forward");
   NUNET_REQUIRE(bnbuf, "plan_forward: bnbuf (running stats) required");
   hipStream_t st = (hipStream_t)s;
   const nunet_plan_cfg& c = P->cfg;
@@ -973,7 +980,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   // prerequisites of everything on the caller's stream, before the fork: both fixed-point sum regions (the
   // BatchNorm statistics of this pass and the BatchNorm-backward sums of the pass that may follow) in one launch
   if (training) CK(nunet_zero_async(AB(arena, P->off_fx), 2 * fx_region_bytes(P), st));
-  CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, (nunet_stream_t)st));
+  if (!staged) CK(nunet_nchw_to_nhwc(input, c.N, c.input_channels, c.H, c.W, dt, AB(arena, P->off_img), 32, (nunet_stream_t)st));
 
   Sched S; S.init(P, st, 0);
   int rc = NUNET_OK;
@@ -1088,9 +1095,70 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   return rc;
 }
 
-extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s);
-extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, nunet_stream_t s) {
-  return nunet_plan_backward_phase(P, params, dlogits, arena, grads, accumulate, 7, s);
+// ---------------------------------------------------------------------------------------------------------
+// Device-side input pipeline straight into the plan's image buffer (reference dataset.py:66-74 + trains.py:258-259,266:
+// Normalize -> /255 -> HWC->CHW, RandomRotate90 / Flip): uint8 NHWC batch -> ((u/255 - mean)/std) * post_scale, rounded
+// to the storage type, as the padded NHWC tile the first conv reads. One thread per pixel writes the pixel's 32 channels
+// (zeros beyond C) as 16-byte stores. The arithmetic is nunet_preprocess_u8's followed by nunet_nchw_to_nhwc's rounding, so
+// the staged image is bit-identical to the float path's; only uint8 crosses PCIe and the per-step layout launch goes away.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stage_u8_kernel(const uint8_t* __restrict__ u, int N, int H, int W, int C, const float* __restrict__ mean,
+                                                       const float* __restrict__ stdv, const int32_t* __restrict__ aug, float post_scale, T* __restrict__ img) {
+  constexpr int EPV = Tr<T>::EPV;
+  const long long npix = (long long)N * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    long long t = i / W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    int sy = y, sx = x;                       // destination (y, x) <- source: undo flips, then the rotation (as preprocess_u8_kernel)
+    const int a = aug ? aug[n] : 0;
+    if (a & 8) sy = H - 1 - sy;
+    if (a & 4) sx = W - 1 - sx;
+    const int k = a & 3;
+    int ry = sy, rx = sx;
+    if (k == 1) { ry = sx; rx = W - 1 - sy; }
+    else if (k == 2) { ry = H - 1 - sy; rx = W - 1 - sx; }
+    else if (k == 3) { ry = H - 1 - sx; rx = sy; }
+    const uint8_t* src = u + (((long long)n * H + ry) * W + rx) * C;
+    T* dst = img + i * 32;
+#pragma unroll
+    for (int v = 0; v < 32 / EPV; ++v) {
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const int c = v * EPV + e;
+        float f = 0.f;
+        if (c < C) {
+          const float m = mean ? mean[c] : 0.f, sd = stdv ? stdv[c] : 1.f;
+          f = (((float)src[c] / 255.f - m) / sd) * post_scale;
+        }
+        o.set(e, f);
+      }
+      st16(dst + v * EPV, o);
+    }
+  }
+}
+template <typename T> static int launch_stage_u8(const uint8_t* u, int N, int H, int W, int C, const float* mean, const float* stdv, const int32_t* aug,
+                                                 float post_scale, void* img, hipStream_t st) {
+  const long long npix = (long long)N * H * W;
+  long long g = (npix + 255) / 256; if (g > 4096) g = 4096;
+  ProfScope ps(PC_LAYOUT, 0, (double)npix * (C + 32.0 * sizeof(T)), st);
+  NUNET_LAUNCH((stage_u8_kernel<T>), dim3((unsigned)g), dim3(256), 0, st, u, N, H, W, C, mean, stdv, aug, post_scale, (T*)img);
+  return nunet_check_launch("plan_stage_u8");
+}
+extern "C" int nunet_plan_stage_u8(nunet_plan* P, const uint8_t* u8_nhwc, const float* mean, const float* stdv, const int32_t* aug, float post_scale,
+                                   void* arena, size_t arena_bytes, nunet_stream_t s) {
+  NUNET_REQUIRE(P && u8_nhwc && arena, "plan_stage_u8: null pointer");
+  ARENA_CHECK("plan_stage_u8");
+  const nunet_plan_cfg& c = P->cfg;
+  return NUNET_DISPATCH(c.dtype, launch_stage_u8, u8_nhwc, c.N, c.H, c.W, c.input_channels, mean, stdv, aug, post_scale, (void*)AB(arena, P->off_img), (hipStream_t)s);
+}
+
+extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, const float* dlogits, void* arena, size_t arena_bytes, float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s);
+extern "C" int nunet_plan_backward(nunet_plan* P, const float* params, const float* dlogits, void* arena, size_t arena_bytes, float* grads, int32_t accumulate, nunet_stream_t s) {
+  return nunet_plan_backward_phase(P, params, dlogits, arena, arena_bytes, grads, accumulate, 7, s);
 }
 
 extern "C" int nunet_plan_grad_scratch(const nunet_plan* P, int64_t* byte_offset, int64_t* bucket0_floats, int64_t* total_floats) {
@@ -1105,9 +1173,10 @@ extern "C" int nunet_plan_grad_scratch(const nunet_plan* P, int64_t* byte_offset
 // `grads` (flat OIHW arena) is optional: when given it receives the (scaled) gradients as nunet_plan_backward would
 // have left them. Afterwards the packed weights in `arena` are current: the next nunet_plan_forward may be called
 // with bit 1 of `training` set (skip the repack).
-extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
+extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, void* arena, size_t arena_bytes, const float* lr_dev, float mom, float wd,
                                  int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s) {
   NUNET_REQUIRE(P && params && momentum && arena && lr_dev, "plan_update: null pointer");
+  ARENA_CHECK("plan_update");
   hipStream_t st = (hipStream_t)s;
   PackTab& tab = P->ptab;
   int nt = 0;
@@ -1220,9 +1289,10 @@ __global__ __launch_bounds__(256) void unpack_sgd_tiled_kernel(UpdP u, PackTab t
   }
 }
 
-extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, void* arena, const float* lr_dev, float mom, float wd,
+extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, void* arena, size_t arena_bytes, const float* lr_dev, float mom, float wd,
                               int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s) {
   NUNET_REQUIRE(P && params && momentum && arena && lr_dev, "plan_sgd: null pointer");
+  ARENA_CHECK("plan_sgd");
   hipStream_t st = (hipStream_t)s;
   UpdP u;
   u.params = params; u.mom = momentum; u.scratch = (const float*)AB(arena, P->off_gs); u.grads = grads; u.lr = lr_dev;
@@ -1239,8 +1309,9 @@ extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, voi
 // Repack the 16-bit weight layouts from the fp32 master parameters (what nunet_plan_forward does first unless told
 // that they are current): needed once before a loop that relies on nunet_plan_update, and after the parameters were
 // changed by anything else (checkpoint load, a stock optimiser).
-extern "C" int nunet_plan_repack(nunet_plan* P, const float* params, void* arena, nunet_stream_t s) {
+extern "C" int nunet_plan_repack(nunet_plan* P, const float* params, void* arena, size_t arena_bytes, nunet_stream_t s) {
   NUNET_REQUIRE(P && params && arena, "plan_repack: null pointer");
+  ARENA_CHECK("plan_repack");
   char* wpack = AB(arena, P->off_wpack);
   if (P->cfg.dtype == NUNET_F32) return launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, (hipStream_t)s);
   if (P->cfg.dtype == NUNET_BF16) return launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, (hipStream_t)s);
@@ -1324,8 +1395,9 @@ static int block_of_slot(const nunet_plan* P, int l, int s) {
 
 // phases: 1 = heads and the last anti-diagonal's blocks (75 % of the gradient bytes);
 //         2 = the remaining blocks; 4 = unpack into the flat OIHW gradient arena. 7 = everything.
-extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, const float* dlogits, void* arena, float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s) {
+extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, const float* dlogits, void* arena, size_t arena_bytes, float* grads, int32_t accumulate, int32_t phases, nunet_stream_t s) {
   NUNET_REQUIRE(P && params && dlogits && arena && grads, "plan_backward: null pointer");
+  ARENA_CHECK("plan_backward");
   hipStream_t st = (hipStream_t)s;
   const nunet_plan_cfg& c = P->cfg;
   const int dt = c.dtype, es = P->es;
@@ -1498,6 +1570,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       w1.dy = dy1; w2.dy = dy2; w1.Cout = w2.Cout = f; w1.PY = w2.PY = f;
       w1.dw = L1.ks > 1 ? slabs + L1.slab : gsr + L1.gs; w1.slab_stride = 9LL * L1.cout * L1.cinpad; w1.max_slabs = L1.ks; w1.target_wgs = L1.wg_target;
       w2.dw = L2.ks > 1 ? slabs + L2.slab : gsr + L2.gs; w2.slab_stride = 9LL * L2.cout * L2.cinpad; w2.max_slabs = L2.ks; w2.target_wgs = L2.wg_target;
+      w1.dw_floats = (int64_t)L1.ks * w1.slab_stride; w2.dw_floats = (int64_t)L2.ks * w2.slab_stride;
       const int alg_cin = (i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
       S.name("B%d%d.wgrad", n.i, n.j);
       int rx[4] = {-1, -1, -1, -1}, r_in = -1, r_up = -1;

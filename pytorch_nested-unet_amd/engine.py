@@ -113,7 +113,7 @@ class Engine:
         L.require_gpu_tensor(inp, torch.float32, "input")
         logits = torch.empty((pl.heads, pl.n, pl.ncls, pl.h, pl.w), dtype=torch.float32, device=self.device)
         L.check(L.lib().nunet_plan_forward(pl.handle, L.ptr(self.flat_params), L.ptr(self.bnbuf), L.ptr(self.nbt),
-                                           L.ptr(inp), L.ptr(pl.arena), L.ptr(logits), 1 if training else 0,
+                                           L.ptr(inp), L.ptr(pl.arena), L.nbytes(pl.arena), L.ptr(logits), 1 if training else 0,
                                            L.stream()), "nunet_plan_forward")
         pl.trained_forward = bool(training)
         return logits
@@ -122,7 +122,7 @@ class Engine:
         if not pl.trained_forward:
             raise L.NunetError("backward needs a training-mode forward (BatchNorm batch statistics) first")
         L.require_gpu_tensor(dlogits, torch.float32, "grad_output")
-        L.check(L.lib().nunet_plan_backward(pl.handle, L.ptr(self.flat_params), L.ptr(dlogits), L.ptr(pl.arena),
+        L.check(L.lib().nunet_plan_backward(pl.handle, L.ptr(self.flat_params), L.ptr(dlogits), L.ptr(pl.arena), L.nbytes(pl.arena),
                                             L.ptr(self.flat_grads), 1 if accumulate else 0, L.stream()),
                 "nunet_plan_backward")
 

@@ -18,9 +18,9 @@ class _BCEDiceFn(torch.autograd.Function):
         n = logits.size(0)
         per = logits.numel() // n
         lib = L.lib()
-        ws = torch.empty(lib.nunet_bce_dice_ws_bytes(n) // 4 + 4, dtype=torch.float32, device=logits.device)   # the library states the size
+        ws = torch.empty((lib.nunet_bce_dice_ws_bytes(n) + 3) // 4, dtype=torch.float32, device=logits.device)   # the library states the size ...
         loss = torch.empty(1, dtype=torch.float32, device=logits.device)
-        L.check(lib.nunet_bce_dice_fwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.ptr(loss), L.stream()),
+        L.check(lib.nunet_bce_dice_fwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.nbytes(ws), L.ptr(loss), L.stream()),   # ... and checks it
                 "nunet_bce_dice_fwd")
         ctx.save_for_backward(logits, target, ws)
         return loss.reshape(())
@@ -32,7 +32,7 @@ class _BCEDiceFn(torch.autograd.Function):
         per = logits.numel() // n
         g = g.contiguous().float()
         dx = torch.empty_like(logits)
-        L.check(L.lib().nunet_bce_dice_bwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.ptr(g), L.ptr(dx),
+        L.check(L.lib().nunet_bce_dice_bwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.nbytes(ws), L.ptr(g), L.ptr(dx),
                                            L.stream()), "nunet_bce_dice_bwd")
         return dx, None
 
@@ -58,7 +58,7 @@ class _LovaszFn(torch.autograd.Function):
         ws = torch.empty(L.lib().nunet_lovasz_ws_bytes(n, per), dtype=torch.uint8, device=logits.device)
         unit = torch.empty_like(logits)
         loss = torch.empty(1, dtype=torch.float32, device=logits.device)
-        L.check(L.lib().nunet_lovasz_hinge_fwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.ptr(unit), L.ptr(loss),
+        L.check(L.lib().nunet_lovasz_hinge_fwd(L.ptr(logits), L.ptr(target), n, per, L.ptr(ws), L.nbytes(ws), L.ptr(unit), L.ptr(loss),
                                                L.stream()), "nunet_lovasz_hinge_fwd")
         ctx.save_for_backward(unit)
         return loss.reshape(())

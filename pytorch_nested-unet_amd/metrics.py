@@ -4,6 +4,34 @@ import torch
 from . import _lib as L
 
 
+_IOU_THR = None
+
+
+def iou_logit_threshold():
+    """The smallest fp32 logit x with `torch.sigmoid(x) > 0.5` as the REFERENCE evaluates it (metrics.py:10-12: fp32 sigmoid
+    on the host, then `> 0.5`). It is not 0: in fp32 sigmoid(x) rounds to exactly 0.5 for 0 < x <~ 6e-8, and those pixels
+    are background in the reference's integer counts. Found once by bisection over fp32 bit patterns with the host's
+    torch.sigmoid (padded to a full vector: torch's scalar tail can differ from its vectorised path by an ulp)."""
+    global _IOU_THR
+    if _IOU_THR is None:
+        import numpy as np
+
+        def fg(bits):
+            xp = np.zeros(256, np.float32)
+            xp[0] = np.array([bits], np.uint32).view(np.float32)[0]
+            return bool(torch.sigmoid(torch.from_numpy(xp)).numpy()[0] > np.float32(0.5))
+        lo, hi = 0, int(np.array([1.0], np.float32).view(np.uint32)[0])     # sigmoid(+0) = 0.5: not foreground; sigmoid(1) is
+        assert not fg(lo) and fg(hi)
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if fg(mid):
+                hi = mid
+            else:
+                lo = mid
+        _IOU_THR = float(np.array([hi], np.uint32).view(np.float32)[0])
+    return _IOU_THR
+
+
 def iou_counts(output, target, counts=None):
     """Device-side (intersection, union) counts as a uint64[2] tensor; no host sync.
     `counts` may be passed to accumulate over several batches."""
@@ -11,7 +39,7 @@ def iou_counts(output, target, counts=None):
     L.require_gpu_tensor(target, torch.float32, "target")
     if counts is None:
         counts = torch.zeros(2, dtype=torch.int64, device=output.device)
-    L.check(L.lib().nunet_iou_counts(L.ptr(output), L.ptr(target), output.numel(), L.ptr(counts), L.stream()),
+    L.check(L.lib().nunet_iou_counts(L.ptr(output), L.ptr(target), output.numel(), iou_logit_threshold(), L.ptr(counts), L.stream()),
             "nunet_iou_counts")
     return counts
 

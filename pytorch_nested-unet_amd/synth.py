@@ -60,15 +60,26 @@ def synth_blob_pairs(n, h, w, seed=1234, cin=3):
     the blob mask - background pixels U{0..199}, nuclei pixels U{56..255} per channel, so a single pixel says
     little (72 % of either range is shared) and the network needs spatial context - then goes through the same uint8 -> Normalize -> /255
     pipeline as synth_images (reference dataset.py:66-74). Returns (image [n,cin,h,w] f32, mask [n,1,h,w] f32)."""
-    msk = synth_masks(n, h, w, 1, seed)
-    rng = np.random.default_rng(seed + 104729)
-    bg = rng.integers(0, 200, size=(n, h, w, cin), dtype=np.int32)
-    fg = rng.integers(56, 256, size=(n, h, w, cin), dtype=np.int32)
-    raw = np.where(msk[:, 0, :, :, None] > 0.5, fg, bg).astype(np.uint8).astype(np.float64)
+    raw8, m8 = synth_blob_pairs_u8(n, h, w, seed, cin)
+    msk = np.ascontiguousarray((m8 > 127).astype(np.float32).transpose(0, 3, 1, 2))
+    raw = raw8.astype(np.float64)
     mean = np.resize(_MEAN, cin)
     std = np.resize(_STD, cin)
     x = ((raw / 255.0 - mean) / std) / 255.0
     return np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32), msk
+
+
+def synth_blob_pairs_u8(n, h, w, seed=1234, cin=3):
+    """The same set as synth_blob_pairs BEFORE the sample pipeline: decoded uint8 images [n,h,w,cin] and uint8 masks
+    [n,h,w,1] in {0,255} - what a reference Dataset holds after cv2.imread (dataset.py:56-64), and what the device-side
+    pipeline (dataset.py of this package, TrainStep(input_u8=True)) takes."""
+    msk = synth_masks(n, h, w, 1, seed)
+    rng = np.random.default_rng(seed + 104729)
+    bg = rng.integers(0, 200, size=(n, h, w, cin), dtype=np.int32)
+    fg = rng.integers(56, 256, size=(n, h, w, cin), dtype=np.int32)
+    raw = np.where(msk[:, 0, :, :, None] > 0.5, fg, bg).astype(np.uint8)
+    m8 = (msk[:, 0, :, :, None] > 0.5).astype(np.uint8) * 255
+    return np.ascontiguousarray(raw), np.ascontiguousarray(m8)
 
 
 def synth_split(n, h, w, cin=3, ncls=1, seed=1000):

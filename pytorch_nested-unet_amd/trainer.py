@@ -29,7 +29,14 @@ from .parallel import allreduce_flat_, broadcast_flat_
 
 class TrainStep:
     def __init__(self, model, batch_shape, lr=1e-3, momentum=0.9, weight_decay=1e-4, nesterov=False,
-                 use_graph=True, process_group=None, keep_grads=True, fused_update=None):
+                 use_graph=True, process_group=None, keep_grads=True, fused_update=None, loss="BCEDiceLoss", input_u8=False):
+        """loss: 'BCEDiceLoss' (reference losses.py:103-117, the default of trains.py:58) or 'LovaszHingeLoss'
+        (losses.py:120-129, the loss of the reference's published table README.md:102-108; one class only) - both run
+        inside the step's graph and under data parallel.
+        input_u8: the step's inputs are the DECODED uint8 batch (images [N,H,W,C], masks [N,H,W,K] in {0,255}) plus optional
+        per-sample augmentation codes; Normalize, /255, the mask scaling, rot90 / flips and the layout change of the
+        reference's sample pipeline (dataset.py:66-74, trains.py:258-266) run as the first two launches of the step's graph
+        (step_u8). Only uint8 crosses PCIe and the per-step NCHW->NHWC launch of the float path is gone."""
         self.model = model
         self.eng = model.engine()
         dev = self.eng.device
@@ -41,10 +48,27 @@ class TrainStep:
         self.heads = self.pl.heads
         self.x = x0
         self.t = torch.zeros((n, self.ncls, h, w), dtype=torch.float32, device=dev)
+        self.input_u8 = bool(input_u8)
+        if self.input_u8:
+            import numpy as np
+            from .dataset import MEAN, STD
+            self.x_u8 = torch.zeros((n, h, w, cin), dtype=torch.uint8, device=dev)
+            self.t_u8 = torch.zeros((n, h, w, self.ncls), dtype=torch.uint8, device=dev)
+            self.aug = torch.zeros(n, dtype=torch.int32, device=dev)
+            self._mean = torch.tensor(np.resize(np.asarray(MEAN, np.float32), cin), device=dev)
+            self._std = torch.tensor(np.resize(np.asarray(STD, np.float32), cin), device=dev)
         self.logits = torch.empty((self.heads, n, self.ncls, h, w), dtype=torch.float32, device=dev)
         self.dlogits = torch.empty_like(self.logits)
         self.per = self.ncls * h * w
-        self.loss_ws = torch.empty(L.lib().nunet_loss_step_ws_bytes(n, self.heads) // 4, dtype=torch.float32, device=dev)
+        kinds = {"BCEDiceLoss": L.LOSS_BCE_DICE, "LovaszHingeLoss": L.LOSS_LOVASZ_HINGE}
+        if loss not in kinds:
+            raise L.NunetError("TrainStep: loss %r is not one of %s" % (loss, sorted(kinds)))
+        if loss == "LovaszHingeLoss" and self.ncls != 1:
+            raise L.NunetError("LovaszHingeLoss squeezes the class dimension (reference losses.py:126-127): num_classes must be 1")
+        self.loss_name, self.loss_kind = loss, kinds[loss]
+        from .metrics import iou_logit_threshold
+        self.iou_thr = iou_logit_threshold()
+        self.loss_ws = torch.empty((L.lib().nunet_loss_step_ws_bytes(n, self.per, self.heads, self.loss_kind) + 7) // 8, dtype=torch.float64, device=dev)
         self.loss_out = torch.zeros(self.heads + 1, dtype=torch.float32, device=dev)   # per head, then their mean
         # device-side epoch meters: [sum of step losses, sum of step IoUs, last intersection, last union]
         self.meters = torch.zeros(4, dtype=torch.float64, device=dev)
@@ -118,15 +142,23 @@ class TrainStep:
     def _fwd_loss(self):
         lib, eng, pl = L.lib(), self.eng, self.pl
         st = L.stream()
+        flags = 3 if (self.fused_update == 1 and self._packed) else 1
+        if self.input_u8:
+            # the sample pipeline on the device: image -> the plan's padded NHWC tile, mask -> {0,1} fp32 NCHW target
+            L.check(lib.nunet_plan_stage_u8(pl.handle, L.ptr(self.x_u8), L.ptr(self._mean), L.ptr(self._std), L.ptr(self.aug), 1.0 / 255.0,
+                                            L.ptr(pl.arena), L.nbytes(pl.arena), st), "plan_stage_u8")
+            L.check(lib.nunet_preprocess_u8(L.ptr(self.t_u8), self.n, self.h, self.w, self.ncls, None, None, L.ptr(self.aug), 1.0,
+                                            L.ptr(self.t), st), "preprocess_u8 (masks)")
+            flags |= 4
         L.check(lib.nunet_plan_forward(pl.handle, L.ptr(eng.flat_params), L.ptr(eng.bnbuf), L.ptr(eng.nbt),
-                                       L.ptr(self.x), L.ptr(pl.arena), L.ptr(self.logits), 3 if (self.fused_update == 1 and self._packed) else 1, st), "plan_forward")
-        L.check(lib.nunet_loss_step(L.ptr(self.logits), L.ptr(self.t), self.n, self.per, self.heads, L.ptr(self.loss_ws),
-                                    L.ptr(self.dlogits), L.ptr(self.loss_out), L.ptr(self.meters), st), "loss_step")
+                                       L.ptr(self.x), L.ptr(pl.arena), L.nbytes(pl.arena), L.ptr(self.logits), flags, st), "plan_forward")
+        L.check(lib.nunet_loss_step(L.ptr(self.logits), L.ptr(self.t), self.n, self.per, self.heads, self.loss_kind, L.ptr(self.loss_ws), L.nbytes(self.loss_ws),
+                                    L.ptr(self.dlogits), L.ptr(self.loss_out), L.ptr(self.meters), self.iou_thr, st), "loss_step")
         pl.trained_forward = True
 
     def _bwd(self, phases):
         eng, pl = self.eng, self.pl
-        L.check(L.lib().nunet_plan_backward_phase(pl.handle, L.ptr(eng.flat_params), L.ptr(self.dlogits), L.ptr(pl.arena),
+        L.check(L.lib().nunet_plan_backward_phase(pl.handle, L.ptr(eng.flat_params), L.ptr(self.dlogits), L.ptr(pl.arena), L.nbytes(pl.arena),
                                                   L.ptr(eng.flat_grads), 0, phases, L.stream()), "plan_backward_phase")
 
     def _fwd_bwd(self):
@@ -137,11 +169,11 @@ class TrainStep:
         """scratch -> SGD -> repacked weights in one launch (replaces unpack + sgd + the next forward's repack)."""
         eng, pl = self.eng, self.pl
         if self.fused_update == 2:      # gradient scratch -> SGD in one launch; the next forward repacks
-            L.check(L.lib().nunet_plan_sgd(pl.handle, L.ptr(eng.flat_params), L.ptr(self.mom), L.ptr(pl.arena), L.ptr(self.lr),
+            L.check(L.lib().nunet_plan_sgd(pl.handle, L.ptr(eng.flat_params), L.ptr(self.mom), L.ptr(pl.arena), L.nbytes(pl.arena), L.ptr(self.lr),
                                            self.momentum, self.wd, 1 if self.nesterov else 0, 1.0 / self.world,
                                            L.ptr(eng.flat_grads) if self.keep_grads else None, L.stream()), "plan_sgd")
             return
-        L.check(L.lib().nunet_plan_update(pl.handle, L.ptr(eng.flat_params), L.ptr(self.mom), L.ptr(pl.arena), L.ptr(self.lr),
+        L.check(L.lib().nunet_plan_update(pl.handle, L.ptr(eng.flat_params), L.ptr(self.mom), L.ptr(pl.arena), L.nbytes(pl.arena), L.ptr(self.lr),
                                           self.momentum, self.wd, 1 if self.nesterov else 0, 1.0 / self.world,
                                           L.ptr(eng.flat_grads) if self.keep_grads else None, L.stream()), "plan_update")
 
@@ -149,7 +181,7 @@ class TrainStep:
         """Repack the plan's 16-bit weights from the fp32 parameters: call after changing the parameters by anything
         other than step() (load_state_dict, a stock optimiser) when fused_update is on."""
         if self.fused_update == 1:
-            L.check(L.lib().nunet_plan_repack(self.pl.handle, L.ptr(self.eng.flat_params), L.ptr(self.pl.arena), L.stream()), "plan_repack")
+            L.check(L.lib().nunet_plan_repack(self.pl.handle, L.ptr(self.eng.flat_params), L.ptr(self.pl.arena), L.nbytes(self.pl.arena), L.stream()), "plan_repack")
             self._packed = True
 
     def _opt(self):
@@ -237,8 +269,13 @@ class TrainStep:
         if not self.use_graph:
             return
         eng = self.eng
-        self.x.copy_(inp)
-        self.t.copy_(target)
+        if self.input_u8:          # (uint8 images, uint8 masks)
+            self.x_u8.copy_(inp)
+            self.t_u8.copy_(target)
+            self.aug.zero_()
+        else:
+            self.x.copy_(inp)
+            self.t.copy_(target)
         snap = [t.clone() for t in (eng.flat_params, eng.bnbuf, eng.nbt, self.mom, self.meters)]
         steps0 = self.steps
         self.sync_weights()            # from here on every step leaves the packed weights current
@@ -320,12 +357,32 @@ class TrainStep:
     def step(self, inp=None, target=None):
         """One training iteration. `inp`/`target` are device tensors (copied into the
         static graph inputs); None re-uses what is already staged."""
+        if inp is not None:
+            if self.input_u8:
+                raise L.NunetError("this TrainStep was built with input_u8=True: feed it with step_u8(images_u8, masks_u8, aug)")
+            self.x.copy_(inp, non_blocking=True)
+            self.t.copy_(target, non_blocking=True)
+        self._run()
+
+    def step_u8(self, images_u8, masks_u8, aug=None):
+        """One training iteration from the decoded uint8 batch (device tensors; images [N,H,W,C], masks [N,H,W,K] with
+        values {0,255}) and optional augmentation codes (dataset.draw_augmentation); needs input_u8=True."""
+        if not self.input_u8:
+            raise L.NunetError("step_u8 needs a TrainStep built with input_u8=True")
+        self.x_u8.copy_(images_u8, non_blocking=True)
+        self.t_u8.copy_(masks_u8, non_blocking=True)
+        if aug is None:
+            self.aug.zero_()
+        else:
+            if self.h != self.w and bool((aug & 1).any()):
+                raise L.NunetError("rot90 by an odd count needs square images")
+            self.aug.copy_(aug, non_blocking=True)
+        self._run()
+
+    def _run(self):
         if self.model._engine is not self.eng or not self.eng.intact():
             raise L.NunetError("the module's parameter arenas were re-homed (moved to another device / parameters replaced) "
                                "after this TrainStep was built: its graphs would update orphaned memory. Build a new TrainStep.")
-        if inp is not None:
-            self.x.copy_(inp, non_blocking=True)
-            self.t.copy_(target, non_blocking=True)
         if self.g_fb is not None:
             if self.dp:
                 self._dp_step(self.g_fb.replay, self.g_b2.replay if self.g_b2 is not None else None, self.g_opt.replay)

@@ -241,13 +241,13 @@ if __name__ == "__main__" and len(sys.argv) == 1:
     run_unet()
 
 
-def run_training_log(epochs=30, train_size=512, val_size=128, bs=16, hw=96, lr=1e-2):
+def run_training_log(epochs=30, train_size=512, val_size=128, bs=16, hw=96, lr=1e-2, loss="BCEDiceLoss", out="train_log_blobs.npz"):
     """'val IoU vs ref' in its offline-feasible form: the REFERENCE model/loss/metric
     trained here with torch.optim.SGD + CosineAnnealingLR (trains.py:229-239) on the seeded synthetic
     blob set, the same shuffle stream as train.py. Commits the per-epoch log as a fixture."""
     torch.manual_seed(41)
     model = ref_archs.NestedUNet(1, 3, False)
-    crit = ref_losses.BCEDiceLoss()
+    crit = getattr(ref_losses, loss)()          # losses.__dict__[config['loss']]() of trains.py:213
     opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, nesterov=False, weight_decay=1e-4)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=epochs, eta_min=1e-5)
     img, msk = synth.synth_blob_pairs(train_size, hw, hw, seed=1000)
@@ -277,7 +277,7 @@ def run_training_log(epochs=30, train_size=512, val_size=128, bs=16, hw=96, lr=1
                 vl.update(crit(o, vt[k:k + bs]).item(), o.size(0)); vi.update(ref_metrics.iou_score(o, vt[k:k + bs]), o.size(0))
         rows.append((ep, lr_now, ml.avg, mi.avg, vl.avg, vi.avg))
         print("train-log epoch", rows[-1], flush=True)
-    np.savez_compressed(os.path.join(HERE, "train_log_blobs.npz"), log=np.array(rows, dtype=np.float64),
+    np.savez_compressed(os.path.join(HERE, out), log=np.array(rows, dtype=np.float64),
                         columns=np.array(["epoch", "lr", "loss", "iou", "val_loss", "val_iou"]),
                         config=np.array([epochs, train_size, val_size, bs, hw, lr]))
 
@@ -285,6 +285,11 @@ def run_training_log(epochs=30, train_size=512, val_size=128, bs=16, hw=96, lr=1
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "trainlog":
     torch.set_num_threads(8)
     run_training_log()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "trainlog_lovasz":
+    # the loss behind the reference's published table (README.md:102-108): a shorter log of the REFERENCE trained with it
+    torch.set_num_threads(8)
+    run_training_log(epochs=10, train_size=256, val_size=64, loss="LovaszHingeLoss", out="train_log_blobs_lovasz.npz")
 
 
 def run_lovasz():

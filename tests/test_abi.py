@@ -19,10 +19,17 @@ def lib():
     return L.lib()
 
 
+def _declared():
+    """every function include/nunet.h (the product boundary) and include/nunet_diag.h (test / diagnostic hooks) declare"""
+    out = set()
+    for h in ("nunet.h", "nunet_diag.h"):
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        out |= set(re.findall(r"\b(nunet_[a-z0-9_]+)\s*\(", hdr))
+    return out - {"nunet_plan"}
+
+
 def test_header_symbols_all_exported_and_bound(lib):
-    hdr = open(os.path.join(ROOT, "include", "nunet.h")).read()
-    declared = set(re.findall(r"\b(nunet_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"nunet_plan"}
+    declared = _declared()
     assert declared, "no declarations parsed"
     raw = C.CDLL(L.LIB_PATH)
     for name in sorted(declared):
@@ -40,8 +47,10 @@ def test_product_library_carries_no_diagnostic_build(lib):
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (nunet_[a-z0-9_]+)", out))
-    hdr = open(os.path.join(ROOT, "include", "nunet.h")).read()
-    declared = set(re.findall(r"\b(nunet_[a-z0-9_]+)\s*\(", hdr)) - {"nunet_plan"}
+    declared = _declared()
+    prod = open(os.path.join(ROOT, "include", "nunet.h")).read()
+    for hook in ("nunet_debug_spin", "nunet_plan_stamps_read", "nunet_plan_set_lanes"):
+        assert hook not in prod, "%s is a diagnostic hook: it belongs in include/nunet_diag.h" % hook
     assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
     mk = open(os.path.join(os.path.dirname(L.LIB_PATH), "csrc", "Makefile")).read()
     assert "NUNET_KSTAMP" not in mk and "NUNET_ABLATE" not in mk

@@ -3,11 +3,15 @@ BN running statistics and short SGD trajectories against (a) golden vectors capt
 from the imported reference and (b) the CPU oracle in fp64 on the same seeded inputs.
 
 Tolerances. north_star asks for logits within 1e-4 (fp32) of the reference CPU
-forward; that is asserted directly on the goldens. Gradients of this network are
+forward; that is asserted directly on the goldens, for every case but one: d_n2_16x16_k1,
+whose level-4 BatchNorm normalises over two 1x1 "images" (it divides by a near-zero
+std, the reference's OWN fp32 logits are further than 1e-4 from an fp64 evaluation),
+is bounded by 4x that measured conditioning error. Gradients of this network are
 ill-conditioned in fp32 (the reference's own fp32 gradients sit ~4e-3 relative from
 an fp64 evaluation), so gradient parity is asserted against the fp64
-oracle with the bound max(4 x reference-fp32 error, 2e-3) per tensor (atomic summation order
-adds run-to-run noise of the same size as the reference's own fp32 error in the 16x16 case)."""
+oracle with the bound max(4 x reference-fp32 error, 1e-3) per tensor. Every reduction of
+the HIP path is order-independent or fixed-order (bit-reproducible runs): no tolerance
+here allows for summation-order noise."""
 import numpy as np
 import pytest
 import torch
@@ -73,10 +77,9 @@ def test_fp32_matches_reference_goldens(name, synth):
     m.train()
     out, loss, iou = run_step(m, x, t, ds)
     outs = out if ds else [out]
-    # north_star: fp32 logits within 1e-4 of the reference. Where the reference's OWN fp32 logits are further than that
-    # from an fp64 evaluation (BatchNorm over two 1x1 "images" at level 4 of the 16x16 case divides by a tiny std) the
-    # bound is 4x that conditioning error instead. (Every per-channel sum is order-independent fixed point and every
-    # other reduction has a fixed tree, so a run is bit-reproducible: no allowance for summation-order noise.)
+    # north_star: fp32 logits within 1e-4 of the reference - asserted as such for every case. The ONE exception is named:
+    # d_n2_16x16_k1, where BatchNorm over two 1x1 "images" at level 4 divides by a tiny std and the reference's OWN fp32
+    # logits are further than 1e-4 from an fp64 evaluation; its bound is 4x that conditioning error.
     with torch.no_grad():
         l64 = O.OracleNet(st, ncls, cin, ds, dtype=torch.float64)(x.double())
         l32 = O.OracleNet(st, ncls, cin, ds, dtype=torch.float32)(x)
@@ -85,7 +88,8 @@ def test_fp32_matches_reference_goldens(name, synth):
         ref = g["logits%d" % k]
         scale = max(1.0, float(np.abs(ref).max()))
         cond = float((l32[k].double() - l64[k]).abs().max()) / scale
-        assert float(np.abs(o.detach().cpu().numpy() - ref).max()) < max(1e-4, 4 * cond) * scale, (name, k, cond)
+        bound = max(1e-4, 4 * cond) if name == "d_n2_16x16_k1" else 1e-4
+        assert float(np.abs(o.detach().cpu().numpy() - ref).max()) < bound * scale, (name, k, cond)
     assert abs(float(loss) - float(g["loss"])) < 2e-5
     # IoU is a hard threshold on logits: allow the flip of a handful of near-zero logits
     assert abs(iou - float(g["iou"])) < 5e-3
@@ -146,20 +150,34 @@ def test_reduced_precision_forward_and_grads(dtype, tol, synth):
     print(dtype, "logit rel err", lerr, "loss", float(loss.detach()), float(g["loss"]))
     assert lerr < tol
     assert abs(float(loss.detach()) - float(g["loss"])) < tol
+    # Gradients: the yardstick is the fp64 oracle with the SAME storage points rounded to the 16-bit type (packed weights,
+    # raw conv outputs, activations, pooled / upsampled tensors and their gradients; exact arithmetic in between) - what
+    # 16-bit storage alone does to this ill-conditioned gradient. Per tensor the HIP path may be at most 1.5x (+2 %) as far
+    # from the exact gradient as that emulation, the medians must agree within 20 %, and the two rounded evaluations
+    # must be closer to each other than to the exact one (the bound used for BASELINE configs[1] below).
+    sdt = torch.bfloat16 if dtype == "bf16" else torch.float16
     o64 = O.OracleNet(st, 1, 3, False, dtype=torch.float64)
     O.bce_dice_loss(o64(x.double()), t.double()).backward()
-    errs = []
+    e64 = O.OracleNet(st, 1, 3, False, dtype=torch.float64, storage=sdt)
+    le = O.bce_dice_loss(e64(x.double()), t.double())
+    le.backward()
+    assert abs(float(loss.detach()) - float(le)) < (2e-3 if dtype == "bf16" else 3e-4)
+    e_hip, e_emu, e_mut = {}, {}, {}
     for nm, p in m.named_parameters():
         if nm.endswith("conv1.bias") or nm.endswith("conv2.bias"):
             continue
-        g64 = o64.params[nm].grad
-        errs.append(float((p.grad.cpu().double() - g64).norm() / (g64.norm() + 1e-30)))
-    print(dtype, "grad rel err max/median", max(errs), float(np.median(errs)))
-    # 16-bit storage of pre-BN tensors on an ill-conditioned gradient (the fp32 reference
-    # itself is ~5e-3 off here; 16-bit rounding is 2^13..2^16 x coarser): direction-level
-    # agreement of every gradient tensor with the fp64 oracle, as with torch autocast
-    assert max(errs) < (0.6 if dtype == "bf16" else 0.25), max(errs)
-    assert float(np.median(errs)) < (0.35 if dtype == "bf16" else 0.15)
+        g64, ge, mine = o64.params[nm].grad, e64.params[nm].grad, p.grad.cpu().double()
+        nrm = float(g64.norm()) + 1e-30
+        e_hip[nm] = float((mine - g64).norm()) / nrm
+        e_emu[nm] = float((ge - g64).norm()) / nrm
+        e_mut[nm] = float((mine - ge).norm()) / nrm
+    med = lambda d: float(np.median(list(d.values())))
+    print(dtype, "grad rel-L2 max / median: HIP vs exact %.3f / %.3f, %s-storage oracle vs exact %.3f / %.3f, HIP vs that oracle %.3f / %.3f"
+          % (max(e_hip.values()), med(e_hip), dtype, max(e_emu.values()), med(e_emu), max(e_mut.values()), med(e_mut)))
+    for nm in e_hip:
+        assert e_hip[nm] <= 1.5 * e_emu[nm] + 0.02, (nm, e_hip[nm], e_emu[nm])
+    assert med(e_hip) <= 1.2 * med(e_emu) + 0.01
+    assert med(e_mut) < med(e_hip)
 
 
 def test_features_match_oracle(synth):
@@ -537,3 +555,149 @@ def test_fused_update_equals_unpack_sgd_pack(dtype, mode, synth):
         ts._packed = False
         ts._fwd_loss()                             # repacks from the fp32 parameters
         assert torch.equal(l1, ts.logits)          # same packed weights, deterministic reductions: bit-identical
+
+
+@pytest.mark.parametrize("ds", [False, True])
+@pytest.mark.parametrize("graph", [False, True])
+def test_lovasz_hinge_inside_the_fused_step(ds, graph, synth):
+    """LovaszHingeLoss (reference losses.py:120-129, the loss of its published table README.md:102-108) as a TrainStep loss:
+    inside the step's graph, under deep supervision the mean over heads (trains.py:118-123). One step against the
+    generic autograd path (module forward -> nunet_amd.losses.LovaszHingeLoss -> backward -> the same SGD step)."""
+    from nunet_amd.trainer import TrainStep
+    n, hw = 4, 32
+    torch.manual_seed(5)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, ds).state_dict().items()}
+    img, msk = synth.synth_blob_pairs(n, hw, hw, seed=31)
+    x, t = torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV)
+    # generic path
+    m0 = nunet_amd.archs.NestedUNet(1, 3, ds)
+    m0.load_state_dict(sd)
+    m0 = m0.to(DEV).train()
+    crit = nunet_amd.losses.LovaszHingeLoss()
+    out = m0(x)
+    outs = out if ds else [out]
+    losses = [crit(o, t) for o in outs]
+    loss = sum(losses) / len(losses)
+    loss.backward()
+    g0 = {k: p.grad.detach().clone() for k, p in m0.named_parameters()}
+    iou0 = nunet_amd.metrics.iou_score(outs[-1], t)
+    opt = torch.optim.SGD(m0.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    opt.step()
+    # fused step
+    m1 = nunet_amd.archs.NestedUNet(1, 3, ds)
+    m1.load_state_dict(sd)
+    m1 = m1.to(DEV).train()
+    ts = TrainStep(m1, (n, 3, hw, hw), lr=1e-2, momentum=0.9, weight_decay=1e-4, loss="LovaszHingeLoss", use_graph=graph)
+    if graph:
+        ts.capture(x, t)
+    ts.reset_meters()
+    ts.step(x, t)
+    tl, ti = ts.epoch_stats()
+    lo = ts.loss_out.tolist()
+    for k, lk in enumerate(losses):
+        assert abs(lo[k] - float(lk)) < 2e-6 * max(1.0, abs(float(lk))), (k, lo[k], float(lk))
+    assert abs(tl - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    assert abs(ti - iou0) < 1e-12
+    for k, p in m1.named_parameters():
+        ref = g0[k]
+        assert float((p.grad - ref).norm()) <= 1e-5 * float(ref.norm()) + 1e-9, k
+    for (k, p), q in zip(m1.named_parameters(), m0.parameters()):
+        assert float((p - q).abs().max()) < 1e-6, k
+    with pytest.raises(L.NunetError):
+        TrainStep(nunet_amd.archs.NestedUNet(2, 3, False).to(DEV), (n, 3, hw, hw), loss="LovaszHingeLoss")    # one class only, as the reference
+
+
+def test_lovasz_training_log_follows_reference(synth):
+    """The REFERENCE trained with LovaszHingeLoss (tests/golden/make_golden.py trainlog_lovasz: 10 epochs of 256 blob
+    images, bs 16, 96x96, SGD 1e-2 / 0.9 / 1e-4, cosine; validation on 64 held-out images) vs the same loop through
+    the fused HIP step in fp32: the loss the reference's only published accuracy table was made with (README.md:102-108)."""
+    from nunet_amd.trainer import TrainStep, cosine_lr
+    from nunet_amd.metrics import iou_counts, iou_from_counts
+    g = load_golden("train_log_blobs_lovasz")
+    ref = g["log"]
+    epochs, train_size, val_size, bs, hw, lr = (int(v) if k < 5 else float(v) for k, v in enumerate(g["config"]))
+    torch.manual_seed(41)
+    m = nunet_amd.archs.NestedUNet(1, 3, False, dtype="fp32").to(DEV).train()
+    img, msk = synth.synth_blob_pairs(train_size, hw, hw, seed=1000)
+    vimg, vmsk = synth.synth_blob_pairs(val_size, hw, hw, seed=2000)
+    x, t = torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV)
+    vx, vt = torch.from_numpy(vimg).to(DEV), torch.from_numpy(vmsk).to(DEV)
+    ts = TrainStep(m, (bs, 3, hw, hw), lr=lr, momentum=0.9, weight_decay=1e-4, loss="LovaszHingeLoss")
+    ts.capture(x[:bs], t[:bs])
+    crit = nunet_amd.losses.LovaszHingeLoss()
+    gen = torch.Generator().manual_seed(41)
+    rows = []
+    for ep in range(epochs):
+        perm = torch.randperm(train_size, generator=gen).to(DEV)
+        ts.set_lr(cosine_lr(lr, 1e-5, ep, epochs))
+        ts.reset_meters()
+        m.train()
+        for k in range(train_size // bs):
+            idx = perm[k * bs:(k + 1) * bs]
+            ts.step(x[idx], t[idx])
+        tl, ti = ts.epoch_stats()
+        m.eval()
+        vl = vi = 0.0
+        with torch.no_grad():
+            for k in range(0, val_size, bs):
+                o = m(vx[k:k + bs].contiguous())
+                vl += float(crit(o, vt[k:k + bs].contiguous())) * bs
+                vi += iou_from_counts(iou_counts(o.contiguous(), vt[k:k + bs].contiguous())) * bs
+        rows.append((tl, ti, vl / val_size, vi / val_size))
+        print("epoch", ep, "hip", rows[-1], "ref", tuple(ref[ep][2:]))
+    rows = np.array(rows)
+    assert np.all(np.isfinite(rows))
+    assert float(ref[-1, 5]) > 0.6, "fixture: the reference itself did not learn the task"
+    # first epoch (nothing has diverged yet) tightly; afterwards bands; the final validation IoU within 0.02
+    assert abs(rows[0, 0] - ref[0, 2]) < 0.03 and abs(rows[0, 1] - ref[0, 3]) < 0.05, (rows[0], ref[0])
+    assert np.all(np.abs(rows[:, 0] - ref[:, 2]) < 0.08), (rows[:, 0], ref[:, 2])
+    half = epochs // 2
+    assert np.all(np.abs(rows[half:, 3] - ref[half:, 5]) <= 0.04), (rows[half:, 3], ref[half:, 5])
+    assert abs(float(rows[-3:, 3].mean()) - float(ref[-3:, 5].mean())) <= 0.02
+    assert np.all(np.abs(rows[half:, 2] - ref[half:, 4]) <= 0.06), (rows[half:, 2], ref[half:, 4])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_step_from_decoded_uint8_batches(dtype, synth):
+    """TrainStep(input_u8=True): the reference's sample pipeline (dataset.py:66-74 Normalize, /255, mask / 255; trains.py:258-259
+    rot90 / flips) runs on the device as the head of the step's graph, writing the plan's padded NHWC image directly.
+    Its steps must equal - bit for bit: the staged image has the float path's arithmetic and rounding - steps of the float
+    TrainStep fed with nunet_amd.dataset.preprocess_images / preprocess_masks of the same uint8 batch and codes."""
+    from nunet_amd.trainer import TrainStep
+    from nunet_amd import dataset as D
+    n, hw = 4, 32
+    torch.manual_seed(9)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, False).state_dict().items()}
+    raw, m8 = synth.synth_blob_pairs_u8(3 * n, hw, hw, seed=77)
+    raw, m8 = torch.from_numpy(raw).to(DEV), torch.from_numpy(m8).to(DEV)
+    codes = [None, torch.tensor([1, 2 | 4, 3 | 8, 12], dtype=torch.int32, device=DEV), D.draw_augmentation(n, torch.Generator().manual_seed(2), DEV)]
+    res = []
+    for u8 in (False, True):
+        m = nunet_amd.archs.NestedUNet(1, 3, False, dtype=dtype)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, input_u8=u8)
+        if u8:
+            ts.capture(raw[:n], m8[:n])
+        else:
+            ts.capture(D.preprocess_images(raw[:n]), D.preprocess_masks(m8[:n]))
+        losses = []
+        for k in range(3):
+            xb, tb = raw[k * n:(k + 1) * n], m8[k * n:(k + 1) * n]
+            ts.reset_meters()
+            if u8:
+                ts.step_u8(xb, tb, codes[k])
+            else:
+                ts.step(D.preprocess_images(xb, codes[k]), D.preprocess_masks(tb, codes[k]))
+            losses.append(ts.epoch_stats())
+        torch.cuda.synchronize()
+        res.append((losses, ts.eng.flat_params.clone(), ts.eng.bnbuf.clone()))
+        if u8:
+            with pytest.raises(L.NunetError):
+                ts.step(D.preprocess_images(raw[:n]), D.preprocess_masks(m8[:n]))     # float tensors into a uint8 step: loud
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    # and the pipeline is the reference's: against the host expression on the first batch
+    img, msk = synth.synth_blob_pairs(3 * n, hw, hw, seed=77)
+    np.testing.assert_allclose(D.preprocess_images(raw[:n]).cpu().numpy(), img[:n], atol=2e-7, rtol=2e-5)
+    assert np.array_equal(D.preprocess_masks(m8[:n]).cpu().numpy(), msk[:n])

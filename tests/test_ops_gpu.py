@@ -12,6 +12,12 @@ pytestmark = pytest.mark.gpu
 import nunet_amd  # noqa: E402
 from nunet_amd import _lib as L  # noqa: E402
 
+@pytest.fixture(autouse=True)
+def _canaries(guard_bands):
+    """every device buffer these tests allocate sits between guard bands that are checked after the test (conftest.py)"""
+    yield
+
+
 DEV = "cuda:0"
 TOL = {L.F32: 2e-5, L.BF16: 1.2e-2, L.F16: 2e-3}   # relative to the output's max |value|
 DT = {L.F32: "fp32", L.BF16: "bf16", L.F16: "fp16"}
@@ -154,7 +160,7 @@ def test_conv3x3_wgrad(dt, shape):
 
 def wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, slabs, max_slabs=0, target=0):
     return L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, p0, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(slabs),
-                       9 * cout * (c0 + c1), max_slabs, target)
+                       9 * cout * (c0 + c1), max_slabs, target, 0 if slabs is None else slabs.numel())
 
 
 def wgrad_run(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, target=0):
@@ -804,3 +810,138 @@ def test_sigmoid_masks_u8(shape):
     ref = torch.from_numpy((torch.sigmoid(x).numpy() * np.float32(255)).astype("uint8"))
     assert torch.equal(got, ref), int((got != ref).sum())
     assert int(ref.max()) == 255 and int(ref.min()) == 0
+
+
+def test_undersized_workspaces_are_refused_without_a_launch():
+    """Every C-ABI entry that takes a caller-owned workspace (or the plan arena) takes its size: a buffer smaller than the
+    library's own *_bytes() answer comes back as NUNET_EINVAL with a message - not as a GPU memory fault (round 2's loss
+    workspace fault went exactly through this gap). The refused calls must not have written anything either: the guard
+    bands of this module's fixture sit right behind the short buffers."""
+    lib = L.lib()
+    n, per = 4, 96 * 96
+    x = torch.randn(n, per, device=DEV)
+    t = (torch.rand(n, per, device=DEV) > 0.5).float()
+    loss = torch.zeros(1, device=DEV)
+    # BCEDice
+    need = lib.nunet_bce_dice_ws_bytes(n)
+    short = torch.zeros(need // 4 - 1, device=DEV)
+    assert lib.nunet_bce_dice_fwd(L.ptr(x), L.ptr(t), n, per, L.ptr(short), L.nbytes(short), L.ptr(loss), L.stream()) == -1
+    assert b"nunet_bce_dice_ws_bytes" in lib.nunet_last_error()
+    assert lib.nunet_bce_dice_bwd(L.ptr(x), L.ptr(t), n, per, L.ptr(short), L.nbytes(short), None, L.ptr(torch.zeros_like(x)), L.stream()) == -1
+    ok = torch.zeros((need + 3) // 4, device=DEV)
+    L.check(lib.nunet_bce_dice_fwd(L.ptr(x), L.ptr(t), n, per, L.ptr(ok), L.nbytes(ok), L.ptr(loss), L.stream()), "exact size is accepted")
+    # fused loss step, both losses
+    dl, lo = torch.zeros(2, n, per, device=DEV), torch.zeros(3, device=DEV)
+    xx = torch.randn(2, n, per, device=DEV)
+    for kind in (L.LOSS_BCE_DICE, L.LOSS_LOVASZ_HINGE):
+        need = lib.nunet_loss_step_ws_bytes(n, per, 2, kind)
+        assert need > 0
+        short = torch.zeros(need // 8 - 1, dtype=torch.float64, device=DEV)
+        rc = lib.nunet_loss_step(L.ptr(xx), L.ptr(t), n, per, 2, kind, L.ptr(short), L.nbytes(short), L.ptr(dl), L.ptr(lo), None, 0.0, L.stream())
+        assert rc == -1 and b"nunet_loss_step_ws_bytes" in lib.nunet_last_error()
+    # Lovasz hinge, small (in-LDS) and large (global sort) images
+    for pp in (per, 256 * 256):
+        need = lib.nunet_lovasz_ws_bytes(n, pp)
+        short = torch.zeros(max(need - 8, 8), dtype=torch.uint8, device=DEV)
+        xl, tl = torch.randn(n, pp, device=DEV), torch.zeros(n, pp, device=DEV)
+        rc = lib.nunet_lovasz_hinge_fwd(L.ptr(xl), L.ptr(tl), n, pp, L.ptr(short), L.nbytes(short), L.ptr(torch.zeros_like(xl)), L.ptr(loss), L.stream())
+        assert rc == -1 and b"nunet_lovasz_ws_bytes" in lib.nunet_last_error()
+    # weight-gradient slabs
+    s0 = torch.zeros(2, 12, 12, 32, dtype=torch.bfloat16, device=DEV)
+    dyb = torch.zeros(2, 12, 12, 32, dtype=torch.bfloat16, device=DEV)
+    probe = wgrad_desc(L.BF16, 2, 12, 12, s0, 32, 32, None, 0, dyb, 32, None, 0, 64)
+    ks = lib.nunet_conv3x3_wgrad_slabs(C.byref(probe))
+    assert ks > 1
+    slabs = torch.zeros((ks - 1) * 9 * 32 * 32, device=DEV)           # one slab short
+    d = wgrad_desc(L.BF16, 2, 12, 12, s0, 32, 32, None, 0, dyb, 32, slabs, 0, 64)
+    assert lib.nunet_conv3x3_wgrad(C.byref(d), L.stream()) == -1 and b"slabs of this launch need" in lib.nunet_last_error()
+    # the plan arena
+    cfg = L.PlanCfg(2, 32, 32, 3, 1, 0, L.BF16, 0)
+    p = lib.nunet_plan_create(C.byref(cfg))
+    try:
+        nb = lib.nunet_plan_arena_bytes(p)
+        arena = torch.zeros(nb - 256, dtype=torch.uint8, device=DEV)
+        params = torch.zeros(lib.nunet_plan_param_count(p), device=DEV)
+        bnb = torch.zeros(lib.nunet_plan_bnbuf_count(p), device=DEV)
+        logits = torch.zeros(1, 2, 1, 32, 32, device=DEV)
+        inp = torch.zeros(2, 3, 32, 32, device=DEV)
+        assert lib.nunet_plan_forward(p, L.ptr(params), L.ptr(bnb), None, L.ptr(inp), L.ptr(arena), L.nbytes(arena), L.ptr(logits), 1, L.stream()) == -1
+        assert b"nunet_plan_arena_bytes" in lib.nunet_last_error()
+        assert lib.nunet_plan_backward(p, L.ptr(params), L.ptr(logits), L.ptr(arena), L.nbytes(arena), L.ptr(params), 0, L.stream()) == -1
+        lr = torch.zeros(1, device=DEV)
+        assert lib.nunet_plan_sgd(p, L.ptr(params), L.ptr(bnb), L.ptr(arena), L.nbytes(arena), L.ptr(lr), 0.9, 1e-4, 0, 1.0, None, L.stream()) == -1
+        assert lib.nunet_plan_update(p, L.ptr(params), L.ptr(bnb), L.ptr(arena), L.nbytes(arena), L.ptr(lr), 0.9, 1e-4, 0, 1.0, None, L.stream()) == -1
+        assert lib.nunet_plan_repack(p, L.ptr(params), L.ptr(arena), L.nbytes(arena), L.stream()) == -1
+    finally:
+        lib.nunet_plan_destroy(p)
+
+
+def test_iou_counts_at_the_sigmoid_threshold():
+    """iou_score thresholds `sigmoid(x) > 0.5` in fp32 (reference metrics.py:10-12). In fp32 the sigmoid of a tiny positive
+    logit rounds to exactly 0.5, so `x > 0` over-counts those pixels; the kernel compares against the smallest logit whose
+    REFERENCE sigmoid exceeds 0.5 (metrics.iou_logit_threshold, bisection with the host's torch.sigmoid). Integer counts
+    must equal the host expression's on every edge value."""
+    thr = nunet_amd.metrics.iou_logit_threshold()
+    assert 0.0 < thr < 1e-6
+    f32 = np.float32
+    below = float(np.nextafter(f32(thr), f32(0)))
+    above = float(np.nextafter(f32(thr), f32(1)))
+    edges = [0.0, -0.0, 1e-30, 1e-12, 1e-9, 2e-8, 5.9e-8, 6e-8, below, thr, above, 1e-7, 1.2e-7, 1e-6, -thr, -1e-9, 1.0, -1.0,
+             float("inf"), float("-inf"), float("nan")]
+    x = np.zeros(256, f32)
+    x[:len(edges)] = np.array(edges, f32)
+    x[len(edges):] = np.linspace(-3e-7, 3e-7, 256 - len(edges)).astype(f32)
+    for tval in (1.0, 0.0):
+        t = np.full(256, tval, f32)
+        a = torch.sigmoid(torch.from_numpy(x)).numpy() > 0.5        # the reference expression (host fp32)
+        b = t > 0.5
+        cnt = nunet_amd.metrics.iou_counts(torch.from_numpy(x).to(DEV), torch.from_numpy(t).to(DEV))
+        assert cnt.tolist() == [int((a & b).sum()), int((a | b).sum())], (tval, cnt.tolist())
+    assert not bool(torch.sigmoid(torch.from_numpy(x))[2] > 0.5) and x[2] > 0      # the case `x > 0` got wrong
+
+
+@pytest.mark.parametrize("kind", ["BCEDiceLoss", "LovaszHingeLoss"])
+@pytest.mark.parametrize("heads", [1, 4])
+def test_loss_step_matches_the_standalone_losses(kind, heads):
+    """nunet_loss_step (what the fused training step runs, trains.py:118-128): loss of every head, their mean, the gradient
+    of the mean, IoU of the LAST head and the epoch meters - against the stand-alone loss entries (themselves pinned to the
+    reference goldens above) and the host IoU expression, for both losses."""
+    from oracle import nunet_oracle as O
+    n, h, w = 3, 40, 56
+    per = h * w
+    g = torch.Generator().manual_seed(17 + heads)
+    x = torch.randn(heads, n, 1, h, w, generator=g) * 1.5
+    x[-1, 0, 0, 0, :8] = torch.tensor([0.0, 1e-9, 5e-8, 9e-8, 1e-7, -1e-9, 2e-7, 0.0])      # sigmoid-threshold edge values in the IoU head
+    t = (torch.rand(n, 1, h, w, generator=g) > 0.6).float()
+    lib = L.lib()
+    k = L.LOSS_BCE_DICE if kind == "BCEDiceLoss" else L.LOSS_LOVASZ_HINGE
+    xd, td = x.to(DEV).contiguous(), t.to(DEV).contiguous()
+    ws = torch.zeros((lib.nunet_loss_step_ws_bytes(n, per, heads, k) + 7) // 8, dtype=torch.float64, device=DEV)
+    dl = torch.full((heads, n, per), 9.0, device=DEV)
+    lo = torch.zeros(heads + 1, device=DEV)
+    meters = torch.zeros(4, dtype=torch.float64, device=DEV)
+    meters[0] = 2.0
+    thr = nunet_amd.metrics.iou_logit_threshold()
+    for _ in range(2):        # twice: the workspace carries nothing over from one call to the next
+        L.check(lib.nunet_loss_step(L.ptr(xd), L.ptr(td), n, per, heads, k, L.ptr(ws), L.nbytes(ws), L.ptr(dl), L.ptr(lo), L.ptr(meters), thr, L.stream()), "loss_step")
+    crit = getattr(nunet_amd.losses, kind)()
+    ref_l, ref_g = [], []
+    for q in range(heads):
+        xq = xd[q].clone().requires_grad_(True)
+        lq = crit(xq, td)
+        (lq / heads).backward()
+        ref_l.append(float(lq.detach()))
+        ref_g.append(xq.grad.reshape(n, per))
+    got_l = lo.tolist()
+    for q in range(heads):
+        assert abs(got_l[q] - ref_l[q]) < 2e-6 * max(1.0, abs(ref_l[q]))
+        np.testing.assert_allclose(dl[q].cpu().numpy(), ref_g[q].cpu().numpy(), atol=1e-9, rtol=2e-5)
+    assert abs(got_l[heads] - sum(ref_l) / heads) < 2e-6 * max(1.0, abs(sum(ref_l) / heads))
+    a = torch.sigmoid(x[-1].reshape(-1)).numpy() > 0.5
+    b = t.reshape(-1).numpy() > 0.5
+    inter, union = int((a & b).sum()), int((a | b).sum())
+    m = meters.tolist()
+    assert m[2] == inter and m[3] == union
+    assert abs(m[1] - 2 * (inter + 1e-5) / (union + 1e-5)) < 1e-12
+    assert abs(m[0] - 2.0 - 2 * got_l[heads]) < 1e-6
+    assert abs(O.iou_score(x[-1], t) - (inter + 1e-5) / (union + 1e-5)) < 1e-12     # the oracle agrees with the host expression

@@ -49,15 +49,20 @@ def parse_args():
     p.add_argument('--num_classes', default=1, type=int)
     p.add_argument('--input_w', default=96, type=int)
     p.add_argument('--input_h', default=96, type=int)
-    p.add_argument('--loss', default='BCEDiceLoss', choices=LOSS_NAMES)   # LovaszHingeLoss runs the generic autograd path
+    p.add_argument('--loss', default='BCEDiceLoss', choices=LOSS_NAMES)   # both losses run inside the fused step (TrainStep)
     p.add_argument('--dataset', default='synthetic_blobs')
     p.add_argument('--optimizer', default='SGD', choices=['Adam', 'SGD'])
     p.add_argument('--lr', '--learning_rate', default=1e-3, type=float)
     p.add_argument('--momentum', default=0.9, type=float)
     p.add_argument('--weight_decay', default=1e-4, type=float)
     p.add_argument('--nesterov', default=False, type=str2bool)
-    p.add_argument('--scheduler', default='CosineAnnealingLR', choices=['CosineAnnealingLR', 'ConstantLR'])
+    p.add_argument('--scheduler', default='CosineAnnealingLR',
+                   choices=['CosineAnnealingLR', 'ReduceLROnPlateau', 'MultiStepLR', 'ConstantLR'])    # reference trains.py:87-88
     p.add_argument('--min_lr', default=1e-5, type=float)
+    p.add_argument('--factor', default=0.1, type=float)
+    p.add_argument('--patience', default=2, type=int)
+    p.add_argument('--milestones', default='1,2', type=str)
+    p.add_argument('--gamma', default=2 / 3, type=float)
     p.add_argument('--early_stopping', default=-1, type=int)
     p.add_argument('--num_workers', default=0, type=int, help='accepted for compatibility; data is generated in-process')
     # additions
@@ -66,12 +71,43 @@ def parse_args():
     p.add_argument('--val_size', default=128, type=int)
     p.add_argument('--seed', default=41, type=int)
     p.add_argument('--gpus', default=0, type=int, help='number of ranks this job was launched with (checked against WORLD_SIZE; 0: do not check)')
+    p.add_argument('--device_pipeline', default=True, type=str2bool,
+                   help='feed the fused step with the decoded uint8 batch and run Normalize, /255, rot90 / flips and the layout change on '
+                        'the device (reference dataset.py:66-74, trains.py:258-266); False: float tensors prepared on the host')
+    p.add_argument('--augment', default=False, type=str2bool, help='RandomRotate90 + Flip per sample (trains.py:258-259), device pipeline only')
     return p.parse_args()
 
 
 def make_split(n, h, w, cin, ncls, seed):
     img, msk = nunet_amd.synth.synth_split(n, h, w, cin, ncls, seed)
     return torch.from_numpy(img), torch.from_numpy(msk)
+
+
+class PlateauLR:
+    """lr_scheduler.ReduceLROnPlateau(optimizer, factor, patience, min_lr) as configured at reference trains.py:240-243
+    (mode 'min', rel threshold 1e-4, no cooldown), stepped with the validation loss (trains.py:325-326)."""
+
+    def __init__(self, lr, factor, patience, min_lr):
+        self.lr, self.factor, self.patience, self.min_lr = lr, factor, patience, min_lr
+        self.best, self.bad = float('inf'), 0
+
+    def step(self, metric):
+        if metric < self.best * (1.0 - 1e-4):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            new = max(self.lr * self.factor, self.min_lr)
+            if self.lr - new > 1e-8:
+                self.lr = new
+            self.bad = 0
+        return self.lr
+
+
+def multistep_lr(base_lr, milestones, gamma, epoch):
+    """lr_scheduler.MultiStepLR closed form (trains.py:244-245). The reference builds it but never steps it
+    (trains.py:323-326 step only the cosine and plateau schedulers); this driver does step it."""
+    return base_lr * gamma ** sum(1 for m in milestones if epoch >= m)
 
 
 def validate(config, data, model, criterion):
@@ -124,14 +160,22 @@ def main():
     val = tuple(v.cuda() for v in make_split(config['val_size'], h, w, config['input_channels'], config['num_classes'], 2000))
     steps = config['train_size'] // (bs * world)          # drop_last=True (trains.py:296); global batch = world x bs
 
-    fused = config['optimizer'] == 'SGD' and config['loss'] == 'BCEDiceLoss'   # TrainStep fuses BCEDice; other losses go through autograd
+    fused = config['optimizer'] == 'SGD' and not (config['loss'] == 'LovaszHingeLoss' and config['num_classes'] != 1)   # TrainStep: SGD, either loss
     if world > 1 and not fused:
-        raise SystemExit('data parallel runs the fused step: --optimizer SGD --loss BCEDiceLoss')
+        raise SystemExit('data parallel runs the fused step: --optimizer SGD')
+    u8 = fused and config['device_pipeline'] and config['input_channels'] == 3 and config['num_classes'] == 1
     if fused:
         model.train()
         ts = TrainStep(model, (bs, config['input_channels'], h, w), lr=config['lr'], momentum=config['momentum'],
-                       weight_decay=config['weight_decay'], nesterov=config['nesterov'])
-        ts.capture(train[0][:bs], train[1][:bs])
+                       weight_decay=config['weight_decay'], nesterov=config['nesterov'], loss=config['loss'], input_u8=u8)
+        if u8:
+            # the decoded set (what the reference's Dataset holds after cv2.imread, dataset.py:56-64) lives in HBM as uint8
+            raw, m8 = nunet_amd.synth.synth_blob_pairs_u8(config['train_size'], h, w, seed=1000)
+            train_u8 = (torch.from_numpy(raw).cuda(), torch.from_numpy(m8).cuda())
+            ts.capture(train_u8[0][:bs], train_u8[1][:bs])
+            aug_gen = torch.Generator().manual_seed(config['seed'] + 1)
+        else:
+            ts.capture(train[0][:bs], train[1][:bs])
     else:
         params = filter(lambda p: p.requires_grad, model.parameters())
         if config['optimizer'] == 'Adam':
@@ -142,9 +186,17 @@ def main():
 
     log = OrderedDict([(k, []) for k in ('epoch', 'lr', 'loss', 'iou', 'val_loss', 'val_iou', 'images_per_sec')])
     best_iou, trigger = 0, 0
+    plateau = PlateauLR(config['lr'], config['factor'], config['patience'], config['min_lr'])
     g = torch.Generator().manual_seed(config['seed'])   # host-side permutation: identical for any device
     for epoch in range(config['epochs']):
-        lr = config['lr'] if config['scheduler'] == 'ConstantLR' else cosine_lr(config['lr'], config['min_lr'], epoch, config['epochs'])
+        if config['scheduler'] == 'CosineAnnealingLR':
+            lr = cosine_lr(config['lr'], config['min_lr'], epoch, config['epochs'])
+        elif config['scheduler'] == 'MultiStepLR':
+            lr = multistep_lr(config['lr'], [int(e) for e in config['milestones'].split(',')], config['gamma'], epoch)
+        elif config['scheduler'] == 'ReduceLROnPlateau':
+            lr = plateau.lr
+        else:
+            lr = config['lr']
         perm = torch.randperm(config['train_size'], generator=g).cuda()
         model.train()
         torch.cuda.synchronize()
@@ -155,7 +207,11 @@ def main():
             for k in range(steps):
                 lo = (k * world + rank) * bs                             # slice `rank` of global batch k
                 idx = perm[lo:lo + bs]
-                ts.step(train[0][idx], train[1][idx])
+                if u8:
+                    aug = nunet_amd.dataset.draw_augmentation(bs, aug_gen, 'cuda') if config['augment'] else None
+                    ts.step_u8(train_u8[0][idx], train_u8[1][idx], aug)
+                else:
+                    ts.step(train[0][idx], train[1][idx])
             tl, ti = ts.epoch_stats()
             if world > 1:                                                # epoch means over all ranks' (equal-sized) batches
                 m = torch.tensor([tl, ti], dtype=torch.float64, device='cuda')
@@ -185,6 +241,8 @@ def main():
         torch.cuda.synchronize()
         ips = steps * bs * world / (time.perf_counter() - t0)
         val_log = validate(config, val, model, criterion)                # every rank: identical replicas, identical numbers
+        if config['scheduler'] == 'ReduceLROnPlateau':
+            plateau.step(val_log['loss'])                                # trains.py:325-326
         trigger += 1
         improved = val_log['iou'] > best_iou
         if rank == 0:
