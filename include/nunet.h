@@ -165,6 +165,9 @@ typedef struct {
   float momentum, eps;
   void* a; int32_t PA;              /* relu(bn(y)) */
   void* pooled; int32_t PP;         /* optional fused MaxPool2d(2,2) of a, or NULL */
+  void* up; int32_t PU;             /* optional fused nn.Upsample(x2, bilinear, align_corners=True) of a -> [N][2H][2W][PU], or NULL:
+                                     * extra workgroups of the same launch interpolate relu(bn(y)) from the raw tensor (every tap
+                                     * rounded to the storage type first, so the result is bit-identical to nunet_upsample2x_fwd(a)) */
 } nunet_bn_fwd_desc;
 int nunet_bn_relu_fwd(const nunet_bn_fwd_desc* d, nunet_stream_t s);
 

@@ -78,7 +78,7 @@ class BnFwdDesc(C.Structure):
                 ("running_mean", _vp), ("running_var", _vp), ("num_batches_tracked", _vp),
                 ("save_mean_invstd", _vp),
                 ("training", _i32), ("momentum", _f32), ("eps", _f32),
-                ("a", _vp), ("PA", _i32), ("pooled", _vp), ("PP", _i32)]
+                ("a", _vp), ("PA", _i32), ("pooled", _vp), ("PP", _i32), ("up", _vp), ("PU", _i32)]
 
 
 class BnBwdDesc(C.Structure):

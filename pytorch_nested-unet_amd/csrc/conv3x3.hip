@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       }
     }
   };
-  static_assert(SM * 16 <= 32, "row-validity mask of the epilogue is one 32-bit word");
+  static_assert(SM * 16 <= 64, "row-validity mask of the epilogue is one 64-bit word");
   // BNR: the y1 vectors of this thread's store units. They are requested BEFORE the last chunk's sweep, i.e. before the
   // next item's staging loads: loads return in order, so the epilogue's wait for them leaves those staging loads in
   // flight (requested in the epilogue, behind them, the wait drained all twelve and cost a memory latency per item).
@@ -485,12 +485,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       gpu[k] = m < BM ? s_gpix[m] : -1;
     }
     // which of this thread's accumulator rows are pixels of the image (all 16*SM reads in flight at once)
-    unsigned rowmask = 0u;
+    unsigned long long rowmask = 0ull;
     if (p.stats) {
 #pragma unroll
       for (int a = 0; a < SM; ++a)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rowmask |= (s_gpix[(wm * SM + a) * 32 + acc_row(i, h)] >= 0 ? 1u : 0u) << (a * 16 + i);
+        for (int i = 0; i < 16; ++i) rowmask |= (s_gpix[(wm * SM + a) * 32 + acc_row(i, h)] >= 0 ? 1ull : 0ull) << (a * 16 + i);
     }
     KSTAMP(kst); ++kst;       // g: row masks / unit pixels read
     __syncthreads();  // every wave finished reading halo/weights: the arena becomes staging
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
           const int m = (wm * SM + a) * 32 + acc_row(i, h);
           const T tv = from_f32<T>(acc[a][b][i] + bias);
           if (!(NUNET_ABLATE & 1024)) s_out[m * OS + cl] = tv;
-          const float d = ((rowmask >> (a * 16 + i)) & 1u) ? to_f32(tv) - bias : 0.f;
+          const float d = ((rowmask >> (a * 16 + i)) & 1ull) ? to_f32(tv) - bias : 0.f;
           s1 += d; s2 += d * d;
           acc[a][b][i] = 0.f;
         }
@@ -944,6 +944,10 @@ template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream
   const long px = (long)d->N * d->H * d->W;
   const long items_std = cout % 64 == 0 ? ceil_div64(px, 128) * (cout / 64) : ceil_div64(px, 256) * (cout / 32);
   const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD);
+  // (round 3, measured and not kept: 576 pixels x 32 channels on 6 waves of 96 x 32 - one balanced round of 256 items at level 0,
+  //  the weight stage shared by 4.5 x the pixels, every B fragment feeding three MFMAs - is 10-30 % SLOWER on every level-0 layer:
+  //  six waves land 2-2-1-1 on the four SIMDs, the nine staging units per thread push the kernel to 256 registers with spills, and
+  //  one workgroup per CU loses what co-resident workgroups still overlap; capping today's kernel at one workgroup per CU costs 20 %.)
   if (small) return launch_conv_cfg<T, 4, 1, 1, 1>(d, st);                              // 128 pixels x 32 channels
   if (cout % 64 == 0) return launch_conv_cfg<T, 2, 2, 2, 1>(d, st);
   return launch_conv_cfg<T, 4, 1, 2, 1>(d, st);
@@ -1009,16 +1013,23 @@ struct WgP {
   unsigned invTX, invTY;   // fastdiv_inv(tilesX), fastdiv_inv(tilesY)
 };
 
-template <typename T> struct WgCfg {
+// A work item covers (32 * A Cout) x (32 * B Cin) x 9 taps. In LDS the two operand tiles are stored as A (B) PLANES of
+// [pixels][32 channels] - each plane is exactly the 64-byte-row image the transposing reads were laid out for (conflict-free),
+// so wider items need no new bank analysis: a fragment of sub-tile a / b is the old read at a plane offset.
+template <typename T, int A_, int B_> struct WgCfg {
+  static constexpr int A = A_, B = B_;
   static constexpr int NT = 192;                      // 3 waves: wave w owns taps 3w..3w+2
   static constexpr int BM = 128, HPMAX = 192;
   static constexpr int EPV = Tr<T>::EPV;
   static constexpr bool F32 = std::is_same<T, float>::value;
-  static constexpr int SR = 32;                       // row stride (elements): 32 channels, no pad
-  static constexpr int UPP = 32 / EPV;                // 16-byte units per pixel row
-  static constexpr int NUD = (BM * UPP + NT - 1) / NT;      // dY units per thread
-  static constexpr int NUA = (HPMAX * UPP + NT - 1) / NT;   // halo units per thread
-  static constexpr int STAGE = (BM + HPMAX) * SR;     // elements per LDS stage
+  static constexpr int SR = 32;                       // row stride of a plane (elements): 32 channels, no pad
+  static constexpr int UPR = 32 / EPV;                // 16-byte units per plane row
+  static constexpr int UPD = UPR * A, UPX = UPR * B;  // units per pixel of the dY / input tile
+  static constexpr int NUD = (BM * UPD + NT - 1) / NT;      // dY units per thread
+  static constexpr int NUA = (HPMAX * UPX + NT - 1) / NT;   // halo units per thread
+  static constexpr int STAGE = (BM * A + HPMAX * B) * SR;   // elements per LDS stage
+  static_assert(NT % UPD == 0 && NT % UPX == 0, "every staging unit of a thread has the same channel segment");
+  static_assert(NUD <= 16 && NUA <= 32, "validity masks");
 };
 
 template <typename T>
@@ -1032,18 +1043,21 @@ template <> struct Frag16<bf16_t> { typedef bf16x8 V; };
 template <> struct Frag16<f16_t> { typedef f16x8 V; };
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-// Work item = (32 Cout) x (32 Cin) x 9 taps of dW over a slice of the 128-pixel tiles. The three
+// Work item = (32 A Cout) x (32 B Cin) x 9 taps of dW over a slice of the 128-pixel tiles. The three
 // waves of a workgroup split the TAPS (3 each) and all walk every pixel of the tile: no cross-wave
-// reduction, 48 accumulator registers per lane. Tiles are double-buffered in LDS; the next tile's
-// global loads are in flight (registers) while the current one multiplies.
-template <typename T, bool ST>
+// reduction, 48 A B accumulator registers per lane. Tiles are double-buffered in LDS; the next tile's
+// global loads are in flight (registers) while the current one multiplies. Compared with 32 x 32 items
+// (A = B = 1) an item reads its dY tile once for 32 B input channels and its input tile once for 32 A
+// output channels, and one fragment feeds A (or B) MFMAs.
+template <typename T, bool ST, int A, int B>
 __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
-  typedef WgCfg<T> C;
-  constexpr int NT = C::NT, BM = C::BM, EPV = C::EPV, SR = C::SR, UPP = C::UPP;
-  __shared__ __attribute__((aligned(16))) T s_stage[2 * C::STAGE];
-  __shared__ int s_hidx[BM];
-  __shared__ int s_mxy[BM];
-  __shared__ int s_hxy[C::HPMAX];
+  typedef WgCfg<T, A, B> C;
+  constexpr int NT = C::NT, BM = C::BM, EPV = C::EPV, SR = C::SR, UPR = C::UPR, UPD = C::UPD, UPX = C::UPX;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  T* const s_stage = reinterpret_cast<T*>(s_dyn);                                   // [2][STAGE]
+  int* const s_hidx = reinterpret_cast<int*>(s_dyn + 2 * C::STAGE * sizeof(T));     // [BM]
+  int* const s_mxy = s_hidx + BM;                                                   // [BM]
+  int* const s_hxy = s_mxy + BM;                                                    // [HPMAX]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -1051,7 +1065,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
   const int cit = bid % p.nCiT; bid /= p.nCiT;
   const int cot = bid % p.nCoT;
   const int split = bid / p.nCoT;
-  const int co0 = cot * 32, ci0 = cit * 32;
+  const int co0 = cot * 32 * A, ci0 = cit * 32 * B;
   const int HW2 = p.TW + 2, HH2 = p.TH + 2;
   const int HP = p.NI * HH2 * HW2;
   const int THW = p.TH * p.TW;
@@ -1087,30 +1101,37 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
 #pragma unroll
   for (int k = 0; k < C::NUD; ++k) {
     const int u = tid + k * NT;
-    const int cde = u < BM * UPP ? s_mxy[u / UPP] : -2;                 // (ni, ly, lx), -1: row past the tile
+    const int cde = u < BM * UPD ? s_mxy[u / UPD] : -2;                 // (ni, ly, lx), -1: row past the tile
     dcode[k] = cde >= 0 ? cde + (1 << 10) + 1 : cde;
     duoff[k] = cde >= 0 ? ((cde >> 20) * p.H + ((cde >> 10) & 1023)) * p.W + (cde & 1023) : 0;
   }
 #pragma unroll
   for (int k = 0; k < C::NUA; ++k) {
     const int u = tid + k * NT;
-    const int cde = u < C::HPMAX * UPP ? s_hxy[u / UPP] : -2;           // (ni, hy, hx): halo coordinates = tile coordinates + 1
+    const int cde = u < C::HPMAX * UPX ? s_hxy[u / UPX] : -2;           // (ni, hy, hx): halo coordinates = tile coordinates + 1
     acode[k] = cde;
     auoff[k] = cde >= 0 ? ((cde >> 20) * p.H + ((cde >> 10) & 1023) - 1) * p.W + (cde & 1023) - 1 : 0;
   }
-  // the channel slice of the forward input this item reads: one source per 16-byte unit
+  // the channel slices this item reads: one source per 16-byte unit of the forward input
   // (C0 is a multiple of 16, so a unit never straddles the two concat sources)
-  const int seg = tid % UPP;                 // same for all units of a thread (NT % UPP == 0)
-  const int cch = ci0 + seg * EPV;
+  const int segx = tid % UPX, segd = tid % UPD;   // same for all units of a thread (NT % UPX == 0, NT % UPD == 0)
+  const int cch = ci0 + segx * EPV;
   const bool cvalid = cch < p.Cin;
+  const int dch = co0 + segd * EPV;
+  const bool dvalid = dch < p.Cout;
   const char* abase; unsigned apb, acb;      // uniform base, pitch in bytes, this thread's channel byte offset
-  if (cch < p.C0) { abase = (const char*)p.src0; apb = (unsigned)p.P0 * (unsigned)sizeof(T); acb = (unsigned)cch * (unsigned)sizeof(T); }
+  // (a thread whose channels lie past Cin - the ragged last input tile of a wide item - loads pixel 0 / channel 0 of source 0
+  //  and writes zeros: never an address formed from a null second source)
+  if (cch < p.C0 || !cvalid) { abase = (const char*)p.src0; apb = (unsigned)p.P0 * (unsigned)sizeof(T); acb = (unsigned)(cvalid ? cch : 0) * (unsigned)sizeof(T); }
   else { abase = (const char*)p.src1; apb = (unsigned)p.P1 * (unsigned)sizeof(T); acb = (unsigned)(cch - p.C0) * (unsigned)sizeof(T); }
   const char* const dbase = (const char*)p.dy;
-  const unsigned dpb = (unsigned)p.PY * (unsigned)sizeof(T), dcb = (unsigned)(co0 + seg * EPV) * (unsigned)sizeof(T);
+  const unsigned dpb = (unsigned)p.PY * (unsigned)sizeof(T), dcb = (unsigned)(dvalid ? dch : 0) * (unsigned)sizeof(T);
+  // LDS position of the thread's units inside a stage: plane (32-channel block) and 16-byte segment of the plane row
+  const int dplane = segd / UPR, dseg = segd % UPR;
+  const int xplane = segx / UPR, xseg = segx % UPR;
 
   Vec16<T> dreg[C::NUD], areg[C::NUA];
-  unsigned vmask = 0u;                       // bit k: dY unit k valid; bit 8 + k: input unit k valid (of the tile held in the registers)
+  unsigned vmd = 0u, vma = 0u;               // bit k: dY / input unit k valid (of the tile held in the registers)
   // pixel of a unit (code, uoff) of the tile at (n0, y0, x0); -1: outside the image
   auto unit_pixel = [&](int code, int uoff, int n0, int y0, int x0, int gp0) {
     const int ni = code >> 20, dy = ((code >> 10) & 1023) - 1, dx = (code & 1023) - 1;
@@ -1133,37 +1154,41 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
     const int y0 = (q1 - q2 * p.tilesY) * p.TH;
     const int n0 = q2 * p.NI;
     const int gp0 = (n0 * p.H + y0) * p.W + x0;
-    unsigned vm = 0u;
+    unsigned md = 0u, ma = 0u;
 #pragma unroll
     for (int k = 0; k < C::NUD; ++k) {
-      const int gp = dcode[k] >= 0 ? unit_pixel(dcode[k], duoff[k], n0, y0, x0, gp0) : -1;
-      vm |= gp >= 0 ? (1u << k) : 0u;
+      const int gp = (dcode[k] >= 0 && dvalid) ? unit_pixel(dcode[k], duoff[k], n0, y0, x0, gp0) : -1;
+      md |= gp >= 0 ? (1u << k) : 0u;
       dreg[k].raw = *reinterpret_cast<const u32x4*>(dbase + ((unsigned)(gp < 0 ? 0 : gp) * dpb + dcb));
     }
 #pragma unroll
     for (int k = 0; k < C::NUA; ++k) {
       const int gp = (acode[k] >= 0 && cvalid) ? unit_pixel(acode[k], auoff[k], n0, y0, x0, gp0) : -1;
-      vm |= gp >= 0 ? (1u << (8 + k)) : 0u;
+      ma |= gp >= 0 ? (1u << k) : 0u;
       areg[k].raw = *reinterpret_cast<const u32x4*>(abase + ((unsigned)(gp < 0 ? 0 : gp) * apb + acb));
     }
-    vmask = vm;
+    vmd = md; vma = ma;
   };
   auto write_tile = [&](int buf) {
     T* sd = s_stage + buf * C::STAGE;
-    T* sa = sd + BM * SR;
+    T* sa = sd + A * BM * SR;
 #pragma unroll
     for (int k = 0; k < C::NUD; ++k)
-      if ((k + 1) * NT <= BM * UPP || dcode[k] != -2) st16(&sd[((tid + k * NT) / UPP) * SR + seg * EPV], (vmask >> k) & 1u ? dreg[k] : zero16<T>());
+      if ((k + 1) * NT <= BM * UPD || dcode[k] != -2) st16(&sd[(dplane * BM + (tid + k * NT) / UPD) * SR + dseg * EPV], (vmd >> k) & 1u ? dreg[k] : zero16<T>());
 #pragma unroll
     for (int k = 0; k < C::NUA; ++k)
-      if ((k + 1) * NT <= C::HPMAX * UPP || acode[k] != -2) st16(&sa[((tid + k * NT) / UPP) * SR + seg * EPV], (vmask >> (8 + k)) & 1u ? areg[k] : zero16<T>());
+      if ((k + 1) * NT <= C::HPMAX * UPX || acode[k] != -2) st16(&sa[(xplane * C::HPMAX + (tid + k * NT) / UPX) * SR + xseg * EPV], (vma >> k) & 1u ? areg[k] : zero16<T>());
   };
 
-  f32x16 acc[3];
+  f32x16 acc[A][B][3];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int a = 0; a < A; ++a)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][t][i] = 0.f;
 
   // this wave's three taps: rows 3w..3w+2 of the 3x3 window = kernel row `wave`
   int toff[3];
@@ -1191,40 +1216,60 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
     const int nmt = mt + p.ksplit;
     if (nmt < p.nMT) load_tile(nmt);   // in flight during the MFMAs below
     const T* sd = s_stage + buf * C::STAGE;
-    const T* sa = sd + BM * SR;
+    const T* sa = sd + A * BM * SR;
     if constexpr (C::F32) {
-#pragma unroll 4
+#pragma unroll 2
       for (int kk = 0; kk < BM / 2; ++kk) {
         const int m = kk * 2 + h;
-        const float av = sd[m * SR + r];
         const int hx = s_hidx[m] * SR + r;
+        float av[A];
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sa[hx + toff[t]], acc[t], 0, 0, 0);
+        for (int a = 0; a < A; ++a) av[a] = sd[(a * BM + m) * SR + r];
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const float xv = sa[b * C::HPMAX * SR + hx + toff[t]];
+#pragma unroll
+            for (int a = 0; a < A; ++a) acc[a][b][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], xv, acc[a][b][t], 0, 0, 0);
+          }
       }
     } else {
       // fragments of k-step kk + 1 are read while k-step kk multiplies (two named register sets); the halo offsets of a
       // lane's rows are tile-invariant and were hoisted out of the tile loop (boff): the k-step used to open with two
       // LDS index reads and a full lgkmcnt(0) round trip before it could even form its addresses
       typedef typename Frag16<T>::V FV;
-      s16x4 fa0[2], fa1[2], fx0[2][3], fx1[2][3];
+      s16x4 fa0[2][A], fa1[2][A], fx0[2][B][3], fx1[2][B][3];
       auto rd = [&](int kk, int sl) {
-        fa0[sl] = tr_read(&sd[aoff + kk * 16 * SR]);
-        fa1[sl] = tr_read(&sd[aoff + (kk * 16 + 4) * SR]);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { fx0[sl][t] = tr_read(&sa[boff0[kk] + t * SR]); fx1[sl][t] = tr_read(&sa[boff1[kk] + t * SR]); }
+        for (int a = 0; a < A; ++a) {
+          fa0[sl][a] = tr_read(&sd[a * BM * SR + aoff + kk * 16 * SR]);
+          fa1[sl][a] = tr_read(&sd[a * BM * SR + aoff + (kk * 16 + 4) * SR]);
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            fx0[sl][b][t] = tr_read(&sa[b * C::HPMAX * SR + boff0[kk] + t * SR]);
+            fx1[sl][b][t] = tr_read(&sa[b * C::HPMAX * SR + boff1[kk] + t * SR]);
+          }
       };
       rd(0, 0);
 #pragma unroll
       for (int kk = 0; kk < BM / 16; ++kk) {
         const int cu = kk & 1;
         if (kk + 1 < BM / 16) rd(kk + 1, cu ^ 1);
-        const s16x8 av = __builtin_shufflevector(fa0[cu], fa1[cu], 0, 1, 2, 3, 4, 5, 6, 7);
+        s16x8 av[A];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const s16x8 bv = __builtin_shufflevector(fx0[cu][t], fx1[cu][t], 0, 1, 2, 3, 4, 5, 6, 7);
-          Mma<T>::mma(acc[t], __builtin_bit_cast(FV, av), __builtin_bit_cast(FV, bv));
-        }
+        for (int a = 0; a < A; ++a) av[a] = __builtin_shufflevector(fa0[cu][a], fa1[cu][a], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const s16x8 bv = __builtin_shufflevector(fx0[cu][b][t], fx1[cu][b][t], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int a = 0; a < A; ++a) Mma<T>::mma(acc[a][b][t], __builtin_bit_cast(FV, av[a]), __builtin_bit_cast(FV, bv));
+          }
       }
     }
     if (nmt < p.nMT) write_tile(buf ^ 1);   // the other stage was last read one iteration ago
@@ -1236,37 +1281,63 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
   // this slice's partial gradient block goes to ITS slab with plain stores (no atomics: 256 workgroups adding
   // 9216 floats each to the same 36.8 KB block serialise memory-side, and the sum would depend on arrival order);
   // nunet_wgrad_reduce / the plan's reduce launch sums the slabs in fixed order
-  const int ci = ci0 + r;
   float* const slab = p.dw + (size_t)split * p.slab_stride;
-  if (ci < p.Cin) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int tap = wave * 3 + t;
+  for (int b = 0; b < B; ++b) {
+    const int ci = ci0 + 32 * b + r;
+    if (ci < p.Cin) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = co0 + acc_row(i, h);
-        if (co < p.Cout) slab[((size_t)tap * p.Cout + co) * p.Cin + ci] = acc[t][i];
-      }
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int tap = wave * 3 + t;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int co = co0 + 32 * a + acc_row(i, h);
+            if (co < p.Cout) slab[((size_t)tap * p.Cout + co) * p.Cin + ci] = acc[a][b][t][i];
+          }
+        }
     }
   }
 }
 
-template <typename T, bool ST>
-__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) { wgrad_body<T, ST>(p, blockIdx.x); }
+template <typename T, bool ST, int A, int B>
+__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) { wgrad_body<T, ST, A, B>(p, blockIdx.x); }
 
 // Two independent weight-gradient problems in ONE launch (the two convolutions of a VGGBlock finish
 // their dY at the same point of the backward pass): one kernel boundary less per block and twice
 // the workgroups to fill the chip.
-template <typename T, bool ST>
+template <typename T, bool ST, int A1, int B1, int A2, int B2>
 __global__ __launch_bounds__(192) void wgrad_pair_kernel(WgP pa, WgP pb, int na) {
-  if ((int)blockIdx.x < na) wgrad_body<T, ST>(pa, blockIdx.x);
-  else wgrad_body<T, ST>(pb, blockIdx.x - na);
+  if ((int)blockIdx.x < na) wgrad_body<T, ST, A1, B1>(pa, blockIdx.x);
+  else wgrad_body<T, ST, A2, B2>(pb, blockIdx.x - na);
 }
 
-// K-split slices of a weight-gradient problem: enough (32 x 32 x 9) work items for `target` workgroups, at most one
+// Item shape of a problem, a pure function of its extents. The kernel is bound by the latency of its staging loads,
+// i.e. by how many workgroups are resident (measured, tools/wgrad_layers.py: the time of a launch is inversely
+// proportional to its workgroup count until registers / LDS cap the residency). 64 output channels per item (2 x 1: the
+// input tile, the bigger of the two, is read once per 64 output channels; 256 registers, two workgroups per CU) win
+// 10-15 % on the levels with enough pixel tiles to keep the K-split wide; 64 input channels per item (1 x 2, for the
+// Cout = 32 level) need 260 registers - one workgroup per CU - and lose 40 %: kept as an instantiation for diagnostics only.
+struct WgTile { int A, B; };
+static WgTile wgrad_tile(int cout, int cin, long long px) {
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("NUNET_WGRAD_TILE"); force = e ? atoi(e) : 0; }   // diagnostics: 11 | 12 | 21: force a shape; 2: 2 x 1 only for Cin >= 128
+  // (inside the multi-lane step the 2 x 1 items LOSE what they win alone - 8160 vs 8330 img/s at 96x96 bs16: at two workgroups per
+  //  CU they leave the chain's kernels less room - so the default stays 32 x 32 items everywhere)
+  if (force == 12) return cin >= 64 ? WgTile{1, 2} : WgTile{1, 1};
+  if (cout % 64 == 0 && (force == 21 || (force == 1 && px >= 4096) || (force == 2 && px >= 4096 && cin >= 128))) return WgTile{2, 1};
+  return WgTile{1, 1};
+}
+template <typename T> static size_t wgrad_lds_bytes(WgTile t) {
+  return ((size_t)2 * (128 * t.A + 192 * t.B) * 32) * sizeof(T) + (size_t)(2 * 128 + 192) * sizeof(int);
+}
+
+// K-split slices of a weight-gradient problem: enough work items for `target` workgroups, at most one
 // slice per 128-pixel tile and at most `max_slabs` (the caller's slab capacity). Pure function of the descriptor.
 static int wgrad_slices(const nunet_wgrad_desc* d, const TileGeom& g) {
-  const int otiles = ceil_div(d->Cout, 32) * ceil_div(d->C0 + d->C1, 32);
+  const WgTile wt = wgrad_tile(d->Cout, d->C0 + d->C1, (long long)d->N * d->H * d->W);
+  const int otiles = ceil_div(d->Cout, 32 * wt.A) * ceil_div(d->C0 + d->C1, 32 * wt.B);
   const int nMT = g.tilesX * g.tilesY * g.tilesG;
   int ks = ceil_div(d->target_wgs > 0 ? d->target_wgs : 256, otiles);
   if (ks > nMT) ks = nMT;
@@ -1281,18 +1352,17 @@ extern "C" int32_t nunet_conv3x3_wgrad_slabs(const nunet_wgrad_desc* d) {
 }
 
 template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p) {
-  typedef WgCfg<T> C;
-  static_assert(C::BM == 128 && C::HPMAX == 192, "nunet_conv3x3_wgrad_slabs assumes this tile");
   p.src0 = d->src0; p.src1 = d->src1; p.C0 = d->C0; p.C1 = d->C1; p.P0 = d->P0; p.P1 = d->P1;
   p.dy = d->dy; p.Cout = d->Cout; p.PY = d->PY; p.dw = d->dw;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->C0 + d->C1;
   p.slab_stride = d->slab_stride > 0 ? d->slab_stride : 9LL * p.Cout * p.Cin;
-  const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, C::BM, C::HPMAX);
+  const TileGeom g = nunet_choose_tile(d->N, d->H, d->W, 128, 192);     // WgCfg::BM, HPMAX
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
   p.SHinv = g.SH ? (unsigned)(((1ull << 32) + g.SH - 1) / g.SH) : 0u;
   p.invTX = fastdiv_inv(g.tilesX); p.invTY = fastdiv_inv(g.tilesY);
-  p.nCoT = ceil_div(p.Cout, 32);
-  p.nCiT = ceil_div(p.Cin, 32);
+  const WgTile wt = wgrad_tile(p.Cout, p.Cin, (long long)p.N * p.H * p.W);
+  p.nCoT = ceil_div(p.Cout, 32 * wt.A);
+  p.nCiT = ceil_div(p.Cin, 32 * wt.B);
   p.nMT = g.tilesX * g.tilesY * g.tilesG;
   p.ksplit = wgrad_slices(d, g);
   return (long)p.nCoT * p.nCiT * p.ksplit;
@@ -1304,31 +1374,76 @@ template <typename T> static void wgrad_prof(const nunet_wgrad_desc* d, const Wg
   bytes = px * (acin + p.Cout) * sizeof(T) + 9.0 * acin * p.Cout * 4;
 }
 
+// (dynamic LDS: the wide items exceed the 64 KB static limit; the attribute is set once per instantiation)
+template <typename K> static void wgrad_allow_lds(K kernel, size_t bytes) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <typename T, bool ST, int A, int B> static void launch_wgrad_one(long grid, const WgP& p, hipStream_t st) {
+  const size_t lds = wgrad_lds_bytes<T>(WgTile{A, B});
+  static bool once = false;
+  if (!once) { wgrad_allow_lds(wgrad_kernel<T, ST, A, B>, lds); once = true; }
+  NUNET_LAUNCH((wgrad_kernel<T, ST, A, B>), dim3((unsigned)grid), dim3(192), lds, st, p);
+}
+template <typename T, bool ST, int A1, int B1, int A2, int B2> static void launch_wgrad_two(long ga, long gb, const WgP& pa, const WgP& pb, hipStream_t st) {
+  const size_t l1 = wgrad_lds_bytes<T>(WgTile{A1, B1}), l2 = wgrad_lds_bytes<T>(WgTile{A2, B2});
+  const size_t lds = l1 > l2 ? l1 : l2;
+  static bool once = false;
+  if (!once) { wgrad_allow_lds(wgrad_pair_kernel<T, ST, A1, B1, A2, B2>, lds); once = true; }
+  NUNET_LAUNCH((wgrad_pair_kernel<T, ST, A1, B1, A2, B2>), dim3((unsigned)(ga + gb)), dim3(192), lds, st, pa, pb, (int)ga);
+}
+
 template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStream_t st) {
-  typedef WgCfg<T> C;
   WgP p;
   const long grid = wgrad_setup<T>(d, p);
   double fl, by; wgrad_prof<T>(d, p, fl, by);
   ProfScope ps(p.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fl, by, st);
-  if (p.SH) NUNET_LAUNCH((wgrad_kernel<T, true>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
-  else NUNET_LAUNCH((wgrad_kernel<T, false>), dim3((unsigned)grid), dim3(C::NT), 0, st, p);
+  const WgTile wt = wgrad_tile(p.Cout, p.Cin, (long long)p.N * p.H * p.W);
+  const int key = wt.A * 10 + wt.B;
+  if (p.SH) {
+    if (key == 21) launch_wgrad_one<T, true, 2, 1>(grid, p, st);
+    else if (key == 12) launch_wgrad_one<T, true, 1, 2>(grid, p, st);
+    else launch_wgrad_one<T, true, 1, 1>(grid, p, st);
+  } else {
+    if (key == 21) launch_wgrad_one<T, false, 2, 1>(grid, p, st);
+    else if (key == 12) launch_wgrad_one<T, false, 1, 2>(grid, p, st);
+    else launch_wgrad_one<T, false, 1, 1>(grid, p, st);
+  }
   return nunet_check_launch("wgrad3x3");
 }
 
 struct WgPairArgs { const nunet_wgrad_desc* a; const nunet_wgrad_desc* b; };
 template <typename T> static int launch_wgrad_pair(const WgPairArgs* w, hipStream_t st) {
-  typedef WgCfg<T> C;
   WgP pa, pb;
   const long ga = wgrad_setup<T>(w->a, pa), gb = wgrad_setup<T>(w->b, pb);
   double fa, ba, fb, bb; wgrad_prof<T>(w->a, pa, fa, ba);
   { const int keep = g_prof_alg_cin; g_prof_alg_cin = 0; wgrad_prof<T>(w->b, pb, fb, bb); g_prof_alg_cin = keep; }
-  ProfScope ps(pa.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fa + fb, ba + bb, st);
-  if ((pa.SH != 0) != (pb.SH != 0)) {   // different tiling modes (different extents): two launches
+  const WgTile ta = wgrad_tile(pa.Cout, pa.Cin, (long long)pa.N * pa.H * pa.W), tb = wgrad_tile(pb.Cout, pb.Cin, (long long)pb.N * pb.H * pb.W);
+  const int key = (ta.A * 10 + ta.B) * 100 + tb.A * 10 + tb.B;
+  // the item-shape pairs a VGGBlock produces (conv1 | conv2): 1x1 | 1x1, 2x1 | 2x1, and the mixed forms of the diagnostic rules;
+  // anything else (different tiling modes, other shape pairs): two launches
+  const bool fused = (pa.SH != 0) == (pb.SH != 0) && (key == 1111 || key == 1211 || key == 2121 || key == 2111 || key == 1121);
+  if (!fused) {
     int rc = launch_wgrad<T>(w->a, st);
-    return rc ? rc : launch_wgrad<T>(w->b, st);
+    if (rc) return rc;
+    const int keep = g_prof_alg_cin; g_prof_alg_cin = 0;
+    rc = launch_wgrad<T>(w->b, st);
+    g_prof_alg_cin = keep;
+    return rc;
   }
-  if (pa.SH) NUNET_LAUNCH((wgrad_pair_kernel<T, true>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
-  else NUNET_LAUNCH((wgrad_pair_kernel<T, false>), dim3((unsigned)(ga + gb)), dim3(C::NT), 0, st, pa, pb, (int)ga);
+  ProfScope ps(pa.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fa + fb, ba + bb, st);
+  if (pa.SH) {
+    if (key == 1111) launch_wgrad_two<T, true, 1, 1, 1, 1>(ga, gb, pa, pb, st);
+    else if (key == 1211) launch_wgrad_two<T, true, 1, 2, 1, 1>(ga, gb, pa, pb, st);
+    else if (key == 2111) launch_wgrad_two<T, true, 2, 1, 1, 1>(ga, gb, pa, pb, st);
+    else if (key == 1121) launch_wgrad_two<T, true, 1, 1, 2, 1>(ga, gb, pa, pb, st);
+    else launch_wgrad_two<T, true, 2, 1, 2, 1>(ga, gb, pa, pb, st);
+  } else {
+    if (key == 1111) launch_wgrad_two<T, false, 1, 1, 1, 1>(ga, gb, pa, pb, st);
+    else if (key == 1211) launch_wgrad_two<T, false, 1, 2, 1, 1>(ga, gb, pa, pb, st);
+    else if (key == 2111) launch_wgrad_two<T, false, 2, 1, 1, 1>(ga, gb, pa, pb, st);
+    else if (key == 1121) launch_wgrad_two<T, false, 1, 1, 2, 1>(ga, gb, pa, pb, st);
+    else launch_wgrad_two<T, false, 2, 1, 2, 1>(ga, gb, pa, pb, st);
+  }
   return nunet_check_launch("wgrad3x3 (pair)");
 }
 

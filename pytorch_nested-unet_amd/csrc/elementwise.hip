@@ -141,7 +141,10 @@ extern "C" int nunet_preprocess_u8(const uint8_t* u8_nhwc, int32_t N, int32_t H,
 // ---------------------------------------------------------------------------
 // BatchNorm (+ReLU) (+2x2 max-pool) forward
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void up_taps(int o, float scale, int n_in, int& i0, int& i1, float& l1);
+__device__ __forceinline__ float up_lerp(float v00, float v01, float v10, float v11, float ly, float lx);
 struct BnFwdP {
+  void* up; int PU; int nb_main; Dec4 dcu;     // fused x2 bilinear upsample of the activation (second block role), or up == NULL
   const void* y; int PY;
   const float* conv_bias; const long long* stats; const float* gamma; const float* beta;
   float* rm; float* rv; int64_t* nbt; float* save;
@@ -167,7 +170,9 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   constexpr int U = 4;   // 16-byte loads kept in flight per thread
   const int ppb0 = blockDim.x / G, pl0 = threadIdx.x / G;
   const int64_t npix0 = (int64_t)p.N * p.H * p.W;
-  const int64_t stride0 = (int64_t)gridDim.x * ppb0;
+  const int nbm = p.up ? p.nb_main : (int)gridDim.x;     // blocks of the BatchNorm role (the rest, if any, upsample)
+  const bool main_role = (int)blockIdx.x < nbm;
+  const int64_t stride0 = (int64_t)nbm * ppb0;
   Vec16<T> v[U];
   auto load_batch = [&](int64_t p0) {
 #pragma unroll
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
     }
   };
   int64_t pix0 = (int64_t)blockIdx.x * ppb0 + pl0;
-  if constexpr (!POOL) { if (pix0 < npix0) load_batch(pix0); }
+  if constexpr (!POOL) { if (main_role && pix0 < npix0) load_batch(pix0); }
   const int H2 = p.H / 2, W2 = p.W / 2;
   const int64_t nq = (int64_t)p.N * H2 * W2;
   Vec16<T> vq[4];
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
     for (int k = 0; k < 4; ++k) vq[k] = ld16((const T*)p.y + (p00 + (k >> 1) * p.W + (k & 1)) * p.PY + cg * EPV);
   };
   const int64_t q0 = (int64_t)blockIdx.x * ppb0 + pl0;
-  if constexpr (POOL) { if (q0 < nq) qload(q0); }
+  if constexpr (POOL) { if (main_role && q0 < nq) qload(q0); }
   // per-channel coefficients once per block (not per thread), block 0 also owns the
   // running-stat update and the saved mean/invstd for backward
   for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
@@ -223,6 +228,34 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
   if (blockIdx.x == 0 && p.training && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
   __syncthreads();
   typedef typename FV<T>::type V;
+  if (p.up && (int)blockIdx.x >= p.nb_main) {
+    // ---- second role: nn.Upsample(x2, bilinear, align_corners) of the activation (archs1.py:83,116-131), straight from the raw
+    // tensor: every tap is relu(bn(y)) ROUNDED to the storage type - the value the first role stores - so the result equals the
+    // stand-alone upsample of the stored activation bit for bit, without waiting for it (one launch less per block on the chain)
+    const int HO = 2 * p.H, WO = 2 * p.W;
+    const float sy = HO > 1 ? (float)(p.H - 1) / (float)(HO - 1) : 0.f;
+    const float sx = WO > 1 ? (float)(p.W - 1) / (float)(WO - 1) : 0.f;
+    const int64_t total = (int64_t)p.N * HO * WO * G;
+    const int64_t nthr = (int64_t)(gridDim.x - p.nb_main) * blockDim.x;
+    for (int64_t i = ((int64_t)blockIdx.x - p.nb_main) * blockDim.x + threadIdx.x; i < total; i += nthr) {
+      int cgu, ox, oy, n; long long o;
+      dec4(p.dcu, i, cgu, o, ox, oy, n);
+      int y0, y1, x0, x1; float ly, lx;
+      up_taps(oy, sy, p.H, y0, y1, ly);
+      up_taps(ox, sx, p.W, x0, x1, lx);
+      const T* b = (const T*)p.y + (int64_t)n * p.H * p.W * p.PY + cgu * EPV;
+      const Vec16<T> r00 = ld16(b + ((int64_t)y0 * p.W + x0) * p.PY), r01 = ld16(b + ((int64_t)y0 * p.W + x1) * p.PY);
+      const Vec16<T> r10 = ld16(b + ((int64_t)y1 * p.W + x0) * p.PY), r11 = ld16(b + ((int64_t)y1 * p.W + x1) * p.PY);
+      const V scu = ldf<T>(&s_sc[cgu * EPV]), shu = ldf<T>(&s_sh[cgu * EPV]);
+      const Vec16<T> v00 = vec_from_f<T>(bn_relu_apply<V>(vec_to_f<T>(r00), scu, shu)), v01 = vec_from_f<T>(bn_relu_apply<V>(vec_to_f<T>(r01), scu, shu));
+      const Vec16<T> v10 = vec_from_f<T>(bn_relu_apply<V>(vec_to_f<T>(r10), scu, shu)), v11 = vec_from_f<T>(bn_relu_apply<V>(vec_to_f<T>(r11), scu, shu));
+      Vec16<T> r;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) r.set(e, up_lerp(v00.get(e), v01.get(e), v10.get(e), v11.get(e), ly, lx));
+      st16((T*)p.up + o * p.PU + cgu * EPV, r);
+    }
+    return;
+  }
   const V sc = ldf<T>(&s_sc[cg * EPV]), sh = ldf<T>(&s_sh[cg * EPV]);
   const int ppb = blockDim.x / G;  // pixels (or quads) per block iteration
   const int pl = threadIdx.x / G;
@@ -254,7 +287,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
         st16((T*)p.a + pix * p.PA + cg * EPV, o);
       }
       st16((T*)p.pooled + q * p.PP + cg * EPV, vec_from_f<T>(mx));
-      q += (int64_t)gridDim.x * ppb;
+      q += (int64_t)nbm * ppb;
       if (q < nq) qload(q);
     }
   }
@@ -269,13 +302,22 @@ template <typename T> static int launch_bn_fwd(const nunet_bn_fwd_desc* d, hipSt
   p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C;
   const int G = d->C / Tr<T>::EPV;
   const int ppb = 256 / G;
-  ProfScope ps(PC_BN_FWD, 0, (double)d->N * d->H * d->W * d->C * sizeof(T) * (d->pooled ? 2.25 : 2.0), st);
+  // optional second role of the launch: the x2 upsample of the activation (extra blocks behind the BatchNorm role's)
+  p.up = d->up; p.PU = d->PU;
+  const int64_t utotal = (int64_t)d->N * 4 * d->H * d->W * G;
+  // (persistent blocks, ~8 outputs per thread: every block pays the coefficient prologue - two dependent global-memory latencies -
+  //  so one block per 256 outputs, the stand-alone upsample's grid, made the fused launch twice as long as the two it replaces)
+  const int nb_up = d->up ? grid_for(utotal, 256 * 8, 1024) : 0;
+  p.dcu = make_dec4(utotal, G, 2 * d->W, 2 * d->H);
+  ProfScope ps(PC_BN_FWD, 0, (double)d->N * d->H * d->W * d->C * sizeof(T) * ((d->pooled ? 2.25 : 2.0) + (d->up ? 5.0 : 0.0)), st);
   if (d->pooled) {
     const int64_t nq = (int64_t)d->N * (d->H / 2) * (d->W / 2);
-    NUNET_LAUNCH((bn_relu_fwd_kernel<T, true>), dim3(grid_for(nq, ppb * 2, 2048)), dim3(256), 0, st, p);
+    p.nb_main = grid_for(nq, ppb * 2, 2048);
+    NUNET_LAUNCH((bn_relu_fwd_kernel<T, true>), dim3(p.nb_main + nb_up), dim3(256), 0, st, p);
   } else {
     const int64_t np = (int64_t)d->N * d->H * d->W;
-    NUNET_LAUNCH((bn_relu_fwd_kernel<T, false>), dim3(grid_for(np, ppb * 4, 2048)), dim3(256), 0, st, p);
+    p.nb_main = grid_for(np, ppb * 4, 2048);
+    NUNET_LAUNCH((bn_relu_fwd_kernel<T, false>), dim3(p.nb_main + nb_up), dim3(256), 0, st, p);
   }
   return nunet_check_launch("bn_relu_fwd");
 }
@@ -286,6 +328,7 @@ extern "C" int nunet_bn_relu_fwd(const nunet_bn_fwd_desc* d, nunet_stream_t s) {
   NUNET_REQUIRE(pow2(d->C) && d->C >= epv && d->C / epv <= 256, "bn_relu_fwd: C=%d must be a power of two in [%d, %d]", d->C, epv, 256 * epv);
   NUNET_REQUIRE(d->PY % epv == 0 && d->PA % epv == 0 && (!d->pooled || d->PP % epv == 0), "bn_relu_fwd: pitch alignment");
   NUNET_REQUIRE(!d->pooled || (d->H % 2 == 0 && d->W % 2 == 0), "bn_relu_fwd: fused pool needs even H, W");
+  NUNET_REQUIRE(!d->up || d->PU % epv == 0, "bn_relu_fwd: fused upsample pitch alignment");
   if (d->training) NUNET_REQUIRE(d->stats && d->save_mean_invstd, "bn_relu_fwd: training needs stats and save buffers");
   else NUNET_REQUIRE(d->running_mean && d->running_var, "bn_relu_fwd: eval needs running stats");
   return NUNET_DISPATCH(d->dtype, launch_bn_fwd, d, (hipStream_t)s);
@@ -617,12 +660,23 @@ extern "C" int nunet_maxpool2x2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t
 // ---------------------------------------------------------------------------
 // Upsample x2, bilinear, align_corners=True
 // ---------------------------------------------------------------------------
+// (contraction off: whether `src - i0` fuses with the multiply into an fma is otherwise decided per call site, and the forward
+//  pass, its backward and the form fused into the BatchNorm launch must agree on the weights to the last bit)
 __device__ __forceinline__ void up_taps(int dst, float scale, int n_in, int& i0, int& i1, float& l1) {
+#pragma clang fp contract(off)
   const float src = scale * (float)dst;
   i0 = (int)src;
   if (i0 > n_in - 1) i0 = n_in - 1;
   i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
   l1 = src - (float)i0;
+}
+// the four-tap interpolation, one explicit operation order for every kernel that evaluates it (the stand-alone upsample and
+// the form fused into the BatchNorm launch must round identically)
+__device__ __forceinline__ float up_lerp(float v00, float v01, float v10, float v11, float ly, float lx) {
+#pragma clang fp contract(off)
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float top = __builtin_fmaf(lx, v01, hx * v00), bot = __builtin_fmaf(lx, v11, hx * v10);
+  return __builtin_fmaf(ly, bot, hy * top);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, int PX, T* __restrict__ y, int PY, int N, int H, int W, int C, Dec4 dc) {
@@ -640,11 +694,9 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
     const T* b = x + (int64_t)n * H * W * PX + cg * EPV;
     const Vec16<T> v00 = ld16(b + ((int64_t)y0 * W + x0) * PX), v01 = ld16(b + ((int64_t)y0 * W + x1) * PX);
     const Vec16<T> v10 = ld16(b + ((int64_t)y1 * W + x0) * PX), v11 = ld16(b + ((int64_t)y1 * W + x1) * PX);
-    const float hy = 1.f - ly, hx = 1.f - lx;
     Vec16<T> r;
 #pragma unroll
-    for (int e = 0; e < EPV; ++e)
-      r.set(e, hy * (hx * v00.get(e) + lx * v01.get(e)) + ly * (hx * v10.get(e) + lx * v11.get(e)));
+    for (int e = 0; e < EPV; ++e) r.set(e, up_lerp(v00.get(e), v01.get(e), v10.get(e), v11.get(e), ly, lx));
     st16(y + o * PY + cg * EPV, r);
   }
 }

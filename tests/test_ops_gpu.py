@@ -251,10 +251,16 @@ def test_bn_relu_fwd(dt, pool, training):
     nbt = torch.tensor([4], dtype=torch.int64, device=DEV)
     save = torch.zeros(2 * c, dtype=torch.float32, device=DEV)
     bias_g, gamma_g, beta_g = bias.to(DEV), gamma.to(DEV), beta.to(DEV)   # keep alive across the launch
+    # the fused x2 upsample of the activation (second block role of the same launch) into a pitched buffer
+    up = torch.full((n, 2 * h, 2 * w, c + 8), 5.0, dtype=tdt(dt), device=DEV)
     d = L.BnFwdDesc(dt, n, h, w, c, L.ptr(yb), c, L.ptr(bias_g), L.ptr(stats), L.ptr(gamma_g), L.ptr(beta_g),
                     L.ptr(rmg), L.ptr(rvg), L.ptr(nbt), L.ptr(save), 1 if training else 0, 0.1, 1e-5,
-                    L.ptr(a, 32 * a.element_size()), 160, L.ptr(pooled), c)
+                    L.ptr(a, 32 * a.element_size()), 160, L.ptr(pooled), c, L.ptr(up), c + 8)
     L.check(L.lib().nunet_bn_relu_fwd(C.byref(d), L.stream()), "bn")
+    # ... equals the stand-alone upsample of the STORED activation bit for bit (every tap is rounded to the storage type first)
+    up_ref = torch.zeros((n, 2 * h, 2 * w, c), dtype=tdt(dt), device=DEV)
+    L.check(L.lib().nunet_upsample2x_fwd(dt, n, h, w, c, L.ptr(a, 32 * a.element_size()), 160, L.ptr(up_ref), c, L.stream()), "up")
+    assert torch.equal(up[..., :c], up_ref) and float((up[..., c:].float() - 5.0).abs().max()) == 0
     rm2, rv2 = rm.clone().double(), rv.clone().double()
     ref = F.relu(F.batch_norm(y.double(), rm2, rv2, gamma.double(), beta.double(), training, 0.1, 1e-5))
     got = to_nchw(a, c, off=32)
