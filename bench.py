@@ -237,7 +237,8 @@ def main():
     if world > 1 or force_dp:
         dp_info = {"backend": dist.get_backend(), "rccl_ranks_seen": dist.get_world_size(), "layout": ts.dp_mode,
                    "layout_chosen_by": "measurement at capture (slowest rank decides)" if ts.dp_choice else "NUNET_DP_MODE / default",
-                   "layout_ms": {"after_pass": ts.dp_choice[0], "bucket0_beside_pass": ts.dp_choice[1]} if ts.dp_choice else None,
+                   "layout_ms": {{1: "exchange_after_pass", 2: "bucket0_event_in_graph", 3: "exchange_inside_graph"}.get(k, str(k)): v
+                                 for k, v in ts.dp_choice.items()} if ts.dp_choice else None,
                    "exchange_mb": ts._scratch.numel() * 4 / 1e6}
 
     ms_per_step = dt / args.steps * 1e3

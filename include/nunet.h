@@ -345,6 +345,11 @@ int nunet_plan_backward(nunet_plan* p, const float* params, const float* dlogits
 /* Backward in phases, for overlapping the data-parallel gradient exchange with the rest of backward:
  * phases bit 0 = clear scratch + heads + the last anti-diagonal's blocks (75 % of the gradient bytes),
  * bit 1 = the remaining blocks, bit 2 = unpack into `grads`. nunet_plan_backward == phases 7.
+ * bit 3 (with bit 0) = leave the pass OPEN: no join - the plan keeps its lanes and dependency state, `s` is not made to wait;
+ * nunet_plan_bucket0_wait(p, s2) then orders another stream behind exactly the kernels that complete the first bucket.
+ * bit 4 (with bit 1) = CONTINUE that open pass on the same `s` and join at its end. A data-parallel caller issues
+ * (1|8), bucket0_wait + the first bucket's exchange on a side stream, (2|16), the second bucket's exchange - eagerly or inside
+ * ONE stream capture, where the exchange becomes a branch of the step's graph beside phase 2.
  * The native-layout fp32 gradient scratch lives in the arena at *byte_offset, in gradient-ready order:
  * its first *bucket0_floats floats are final after phase 1, all *total_floats after phase 2; a
  * data-parallel caller all-reduces those two ranges (sum) and then runs phase 4. */
@@ -357,7 +362,9 @@ int nunet_plan_grad_scratch(const nunet_plan* p, int64_t* byte_offset, int64_t* 
  * nunet_plan_bucket0_enable(p, 1) returns 1 when armed (0: not available for this plan, <0: error): a later backward call
  * with phases 1|2 together then records an event as soon as the first *bucket0_floats gradients are final - as an external
  * event record node when the call is captured into a graph. nunet_plan_bucket0_wait(p, s) makes stream `s` wait for the
- * most recent such record: call it after launching the pass (or the graph that holds it), then all-reduce bucket 0 on `s`. */
+ * most recent such record: call it after launching the pass (or the graph that holds it), then all-reduce bucket 0 on `s`.
+ * With an OPEN pass (nunet_plan_backward_phase bit 3) nunet_plan_bucket0_wait needs no arming: `s` waits for the first bucket's
+ * producing kernels directly (inside a capture `s` must be a stream the capture has not used yet). */
 int nunet_plan_bucket0_enable(nunet_plan* p, int32_t on);
 int nunet_plan_bucket0_wait(nunet_plan* p, nunet_stream_t s);
 /* Fused optimiser step on the plan's buffers, replacing unpack (nunet_plan_backward_phase bit 2) + nunet_sgd_step +

@@ -18,6 +18,9 @@ int nunet_plan_set_lanes(nunet_plan* p, nunet_stream_t* lanes, int32_t n);
  * last forward (pass 0) / backward (pass 1), labels one per line ("L<lane> B<i><j>.<op>").
  * Works inside hipGraph replays, where a profiler's dispatch overhead would distort the timeline. */
 int nunet_plan_stamps_read(nunet_plan* plan, int32_t pass, uint64_t* ticks, int32_t cap, int32_t* n_out, char* labels, int32_t label_bytes);
+/* Diagnostic: a 1-thread kernel on `stream` stores the chip-wide 100 MHz clock to *dst when it runs (works inside a hipGraph:
+ * when did this point of the graph execute, relative to another stamp). */
+int nunet_debug_stamp(uint64_t* dst, nunet_stream_t stream);
 /* Diagnostic (tools/graph_sched_probe.py): `tag` workgroups, the first spins `us` microseconds. */
 int nunet_debug_spin(int32_t us, int32_t tag, nunet_stream_t stream);
 

@@ -161,6 +161,7 @@ _SIG = {
     "nunet_profile_begin": (_i32, []),
     "nunet_profile_end": (_i32, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
     "nunet_debug_spin": (_i32, [_i32, _i32, _vp]),
+    "nunet_debug_stamp": (_i32, [_vp, _vp]),
     "nunet_graph_begin": (_i32, [_vp]),
     "nunet_graph_end": (_i32, [_vp, C.POINTER(_vp)]),
     "nunet_graph_launch": (_i32, [_vp, _vp]),

@@ -456,6 +456,8 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   unsigned long long* stamps;              // device, [2][STAMP_CAP]
   hipEvent_t b0_event;                     // recorded when the first gradient bucket (phase-1 nodes + heads) is complete
   bool b0_enabled;
+  struct Sched* open_sched;                // backward pass left open after phase 1 (nunet_plan_backward_phase bit 3): lanes, dependency state
+  std::vector<hipEvent_t> b0_events;       // ... and the last-writer events of the first bucket's gradients, for nunet_plan_bucket0_wait
   std::vector<std::string> stamp_labels[2];
 };
 void graph_tag_tail(hipStream_t st, int lane);   // graph.hip: lane bookkeeping of an active nunet_graph capture
@@ -678,7 +680,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->lanes_external = false;
   rt->cap_next = 0;
   rt->stamps = nullptr;
-  rt->b0_event = nullptr; rt->b0_enabled = false;
+  rt->b0_event = nullptr; rt->b0_enabled = false; rt->open_sched = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
   { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
   for (int l = 0; l < NLANES; ++l) {
@@ -692,9 +694,11 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
 
 static PlanRt* rt_of(nunet_plan* P) { return P->rt; }
 
+static void sched_free(struct Sched* s);
 extern "C" void nunet_plan_destroy(nunet_plan* p) {
   if (!p) return;
   if (p->rt) {
+    if (p->rt->open_sched) { sched_free(p->rt->open_sched); p->rt->open_sched = nullptr; }
     if (!p->rt->lanes_external)
       for (int l = 0; l < NLANES; ++l) if (p->rt->lanes[l]) (void)hipStreamDestroy(p->rt->lanes[l]);
     for (size_t k = 0; k < p->rt->cap_streams.size(); ++k) (void)hipStreamDestroy(p->rt->cap_streams[k]);
@@ -878,6 +882,8 @@ struct Sched {
       if (used[l] && lane_tail[l]) (void)hipStreamWaitEvent(main_s, lane_tail[l], 0);
   }
 };
+
+static void sched_free(Sched* s) { delete s; }
 
 void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
   const int pass = pass_;
@@ -1428,8 +1434,22 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
   const int k_split = nnodes - P->first_phase_nodes;      // phase 1: nodes [k_split, nnodes); phase 2: [0, k_split)
   const int k_hi = (phases & 1) ? nnodes - 1 : k_split - 1;
   const int k_lo = (phases & 2) ? 0 : k_split;
-
-  Sched S; S.init(P, st, 1);
+  // bit 3: leave the pass OPEN after this call - no join: the lanes, their tails and the dependency tracker stay alive in the plan,
+  // the caller's stream is not made to wait for anything, and nunet_plan_bucket0_wait(P, s2) orders another stream behind exactly
+  // the gradients of the first bucket; bit 4: CONTINUE that open pass (its lanes, its tracker) instead of forking anew, and join at
+  // the end. Together they let a data-parallel caller put the first bucket's exchange BESIDE phase 2 inside one captured graph
+  // without the fork / join barrier that cutting the pass into two calls used to cost.
+  const bool leave_open = (phases & 8) != 0, cont = (phases & 16) != 0;
+  PlanRt* const rt = rt_of(P);
+  NUNET_REQUIRE(!cont || rt->open_sched, "plan_backward: phase bit 4 (continue) without an open pass");
+  NUNET_REQUIRE(!(leave_open && (phases & 4)), "plan_backward: an open pass cannot unpack (bit 2)");
+  if (!cont && rt->open_sched) { sched_free(rt->open_sched); rt->open_sched = nullptr; }     // an abandoned open pass
+  Sched* const Sp = cont ? rt->open_sched : new Sched();
+  Sched& S = *Sp;
+  if (!cont) S.init(P, st, 1);
+  else NUNET_REQUIRE(S.main_s == st, "plan_backward: continue on the stream the open pass was started on");
+  rt->open_sched = nullptr;
+  struct Owner { Sched* s; PlanRt* rt; bool keep; ~Owner() { if (keep) rt->open_sched = s; else sched_free(s); } } owner{Sp, rt, false};
   int rc = NUNET_OK;
   const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
   // reduce pass of block kt's second BatchNorm, for the kernel that completes its output gradient
@@ -1630,6 +1650,22 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     }
   }
   if (rc == NUNET_OK) rc = S.run_ops();
+  if (leave_open && rc == NUNET_OK && !S.failed) {
+    // the producers of the first bucket: last-writer events of every gradient resource of the phase-1 nodes and the heads
+    // (single-lane issue: none - everything is in order on the caller's stream, which the caller makes its side stream wait for)
+    rt->b0_events.clear();
+    auto take = [&](int r) {
+      if (!S.multi) return;
+      hipEvent_t e = S.res[r].w_ev;
+      if (!e) return;
+      for (hipEvent_t q : rt->b0_events) if (q == e) return;
+      rt->b0_events.push_back(e);
+    };
+    for (int kk = k_split; kk < nnodes; ++kk) { take(R_GSW + 2 * kk); take(R_GSW + 2 * kk + 1); take(R_GSV + 2 * kk); take(R_GSV + 2 * kk + 1); }
+    for (size_t h = 0; h < P->heads.size(); ++h) take(R_GSV + 30 + (int)h);
+    owner.keep = true;
+    return NUNET_OK;
+  }
   S.join();
   if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_backward: lane scheduler overflow (capture stream pool / dependency lists)"); rc = NUNET_EINVAL; }
   if (rc) return rc;
@@ -1657,7 +1693,15 @@ extern "C" int nunet_plan_bucket0_enable(nunet_plan* P, int32_t on) {
   return rt->b0_enabled ? 1 : 0;     // 1: armed; 0: not available for this plan (callers exchange after the pass)
 }
 extern "C" int nunet_plan_bucket0_wait(nunet_plan* P, nunet_stream_t s) {
-  NUNET_REQUIRE(P && rt_of(P)->b0_event && rt_of(P)->b0_enabled, "plan_bucket0_wait: not enabled");
+  NUNET_REQUIRE(P, "plan_bucket0_wait: null plan");
+  if (rt_of(P)->open_sched) {
+    // an open pass (backward phase bit 3): `s` waits for the kernels that complete the first bucket, nothing else. While the pass is
+    // being captured `s` must be a stream the capture has not used (it joins the capture here, as a lane continuation does).
+    for (hipEvent_t e : rt_of(P)->b0_events)
+      if (hipStreamWaitEvent((hipStream_t)s, e, 0) != hipSuccess) { nunet_set_error("plan_bucket0_wait: %s", hipGetErrorString(hipGetLastError())); return NUNET_ELAUNCH; }
+    return NUNET_OK;
+  }
+  NUNET_REQUIRE(rt_of(P)->b0_event && rt_of(P)->b0_enabled, "plan_bucket0_wait: neither an open pass nor the bucket-0 event is armed");
   if (hipStreamWaitEvent((hipStream_t)s, rt_of(P)->b0_event, 0) != hipSuccess) { nunet_set_error("plan_bucket0_wait: %s", hipGetErrorString(hipGetLastError())); return NUNET_ELAUNCH; }
   return NUNET_OK;
 }
@@ -1681,6 +1725,12 @@ extern "C" int nunet_plan_stamps_read(nunet_plan* P, int32_t pass, uint64_t* tic
   labels[o] = 0;
   *n_out = n;
   return NUNET_OK;
+}
+
+extern "C" int nunet_debug_stamp(uint64_t* dst, nunet_stream_t s) {
+  NUNET_REQUIRE(dst, "debug_stamp: null pointer");
+  NUNET_LAUNCH(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, (unsigned long long*)dst);
+  return nunet_check_launch("debug_stamp");
 }
 
 extern "C" int nunet_plan_set_lanes(nunet_plan* P, nunet_stream_t* lanes, int32_t n) {

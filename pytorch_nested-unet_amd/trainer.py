@@ -86,12 +86,17 @@ class TrainStep:
         # so that bucket 0's exchange runs beside phase 2. Measured on one MI355X (single-rank RCCL group,
         # NUNET_FORCE_DP=1 python bench.py): the cut costs 350-500 us per step (phase 1 is the anti-diagonal's dependency chain with nothing
         # beside it, 2.71 ms vs 2.18 ms) - more than the 36.7 MB exchange it hides is expected to take on >= 4 GPUs.
-        # NUNET_DP_MODE unset / "auto": with more than one rank, capture() times layouts 1 and 2 on the real exchange and
+        # 3: the whole step is ONE graph that contains both exchanges as nodes: the backward pass is issued as phase 1 left open
+        # (nunet_plan_backward_phase bit 3: no join), the first bucket's all-reduce goes to a side stream that waits for exactly
+        # the kernels producing it, phase 2 continues on the open lanes beside it, the second bucket and the optimiser step
+        # follow the join. Overlap without a fork / join barrier inside the pass and without any host call during the step
+        # (RCCL only: a gloo exchange is a host round trip and cannot be captured).
+        # NUNET_DP_MODE unset / "auto": with more than one rank, capture() times layouts 1 and 3 on the real exchange and
         # keeps the faster (the decision is all-reduced, so every rank takes the same one); one rank: layout 1.
         mode = os.environ.get("NUNET_DP_MODE", "auto")
         self.dp_auto = mode == "auto" and self.dp
         self.dp_mode = 1 if mode == "auto" else int(mode)
-        self.dp_choice = None        # (ms layout 1, ms layout 2) when the layout was chosen by measurement
+        self.dp_choice = None        # {layout: ms per step} when the layout was chosen by measurement
         self.use_graph = use_graph
         # optimiser step layout: 0 = unpack, SGD, (next forward's) pack as three streaming launches; 2 (default) = unpack
         # with the SGD step as its epilogue (nunet_plan_sgd, 46 us against 59 us for the pair); 1 = one tile kernel that
@@ -247,7 +252,34 @@ class TrainStep:
                 h.wait()
         run3()
 
+    def _in_graph_exchange_step(self):
+        """Layout 3: forward, loss, the backward pass with both gradient exchanges and the optimiser step as one stream of
+        work - captured, one graph. Bucket 0 (heads + the last anti-diagonal, 75 % of the bytes) is all-reduced on a side stream
+        ordered behind its producing kernels only, while phase 2 continues on the pass's open lanes."""
+        lib, pl = L.lib(), self.pl
+        b0, b1 = self._buckets
+        self._fwd_loss()
+        self._bwd(1 | 8)                                   # phase 1, pass left open: the current stream has waited for nothing
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()                         # (a stream this capture has not used: it joins the capture by its waits)
+        side.wait_stream(cur)                              # single-lane issue keeps everything on `cur`; with lanes this is the fork point only
+        L.check(lib.nunet_plan_bucket0_wait(pl.handle, side.cuda_stream), "plan_bucket0_wait")
+        with torch.cuda.stream(side):
+            h0 = dist.all_reduce(b0, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._bwd(2 | 16)                                  # phase 2 on the open lanes, beside the exchange; joins `cur`
+        # the second bucket is ISSUED before `cur` waits for the first: the collective stream then never waits on an event that
+        # descends from its own tail (the stream-capture pattern ROCm 7.2 crashes on, tests/test_capture_gpu.py); the collective
+        # stream is in order, so waiting for the second exchange covers the first
+        h1 = dist.all_reduce(b1, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        h1.wait()
+        self._side, self._h0 = side, h0                    # (kept alive until the next step)
+        if not self.fused_update:
+            self._bwd(4)
+        self._opt()
+
     def _eager_step(self):
+        if self.dp and self.dp_mode == 3:
+            return self._in_graph_exchange_step()
         if self.dp:
             one_pass = self.dp_mode in (1, 2)     # the bucket-0 event is recorded by a pass that runs both phases together
             self._dp_step((lambda: (self._fwd_loss(), self._bwd(3))) if one_pass else (lambda: (self._fwd_loss(), self._bwd(1))),
@@ -286,6 +318,8 @@ class TrainStep:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if self.dp and self.dp_mode == 3 and dist.get_backend(self.pg) == "gloo":
+            self.dp_mode = 1                                # a host-side exchange cannot be a graph node
         if not self.dp:
             # the whole step as ONE hipGraph (csrc/graph.hip), captured on a side stream, replayed on the caller's
             self.g_fb = _NativeGraph(s, lambda: (self._fwd_bwd(), self._opt()))
@@ -294,7 +328,9 @@ class TrainStep:
                 self._choose_layout(s)
             if self.dp_mode in (1, 2):
                 self._capture_one_pass(s)
-        if self.dp and self.dp_mode not in (1, 2):
+            elif self.dp_mode == 3:
+                self._capture_in_graph_exchange(s)
+        if self.dp and self.dp_mode not in (1, 2, 3):
             self.g_fb = torch.cuda.CUDAGraph()          # forward + loss + backward phase 1
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):   # (the RCCL watchdog thread polls events meanwhile)
                 self._fwd_loss()
@@ -322,17 +358,26 @@ class TrainStep:
         self.g_b2 = None
         self.g_opt = _NativeGraph(s, lambda: (None if self.fused_update else self._bwd(4), self._opt()))
 
+    def _capture_in_graph_exchange(self, s):
+        """Layout 3: the whole data-parallel step, exchanges included, as one graph."""
+        self.g_fb = _NativeGraph(s, self._in_graph_exchange_step)
+        self.g_b2 = self.g_opt = None
+
     def _choose_layout(self, s, reps=8):
-        """Time layout 1 (one exchange after the pass) against layout 2 (bucket 0 exchanged beside the rest of the
-        backward pass) on the real process group and keep the faster. The caller restores the training state."""
+        """Time layout 1 (one exchange after the pass) against layout 3 (both exchanges inside the step's graph, bucket 0
+        beside phase 2 of the backward pass) on the real process group and keep the faster. The caller restores the
+        training state. (Layout 2 - an event recorded inside the graph - stays selectable but is not a candidate: ROCm 7.2
+        releases a waiter on such an event only when the graph ends, tests/test_dist_gpu.py.)"""
         times = []
-        for mode in (1, 2):
+        modes = (1, 3) if dist.get_backend(self.pg) != "gloo" else (1,)
+        for mode in modes:
             self.dp_mode = mode
-            self._capture_one_pass(s)
-            if mode == 2 and not self._b0_armed:
-                times.append(float("inf"))
-                continue
-            run = lambda: self._dp_step(self.g_fb.replay, None, self.g_opt.replay)
+            if mode == 3:
+                self._capture_in_graph_exchange(s)
+                run = self.g_fb.replay
+            else:
+                self._capture_one_pass(s)
+                run = lambda: self._dp_step(self.g_fb.replay, None, self.g_opt.replay)
             for _ in range(2):
                 run()
             torch.cuda.synchronize()
@@ -350,8 +395,8 @@ class TrainStep:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)     # the slowest rank decides, identically everywhere
         t = t.tolist()
-        self.dp_choice = (t[0], t[1])
-        self.dp_mode = 2 if t[1] < t[0] else 1
+        self.dp_choice = {m: v for m, v in zip(modes, t)}
+        self.dp_mode = min(self.dp_choice, key=self.dp_choice.get)
         self.g_fb = self.g_opt = None
 
     def step(self, inp=None, target=None):
@@ -384,7 +429,7 @@ class TrainStep:
             raise L.NunetError("the module's parameter arenas were re-homed (moved to another device / parameters replaced) "
                                "after this TrainStep was built: its graphs would update orphaned memory. Build a new TrainStep.")
         if self.g_fb is not None:
-            if self.dp:
+            if self.dp and self.dp_mode != 3:
                 self._dp_step(self.g_fb.replay, self.g_b2.replay if self.g_b2 is not None else None, self.g_opt.replay)
             else:
                 self.g_fb.replay()

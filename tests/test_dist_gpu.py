@@ -240,5 +240,94 @@ def test_rccl_two_gpus_replicas_stay_identical():
     assert len(res) == 2 and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert np.array_equal(res[0][0], res[1][0])
     assert np.isfinite(res[0][1]) and np.isfinite(res[1][1])
-    assert res[0][2] == res[1][2] and res[0][2] in (1, 2)          # the same measured layout on both ranks
-    print("layout chosen:", res[0][2], "ms (layout 1, layout 2):", res[0][3])
+    assert res[0][2] == res[1][2] and res[0][2] in (1, 3)          # the same measured layout on both ranks
+    print("layout chosen:", res[0][2], "ms per layout:", res[0][3])
+
+
+def _in_graph_worker(port, q):
+    os.environ.update(NUNET_FORCE_DP="1", NUNET_DEBUG_SPIN_US="2000", RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes as C
+    import torch.distributed as dist
+    import nunet_amd
+    from nunet_amd import _lib as L
+    from nunet_amd import trainer as TR
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    synth = nunet_amd.synth
+    batches = []
+    for k in range(3):
+        img, msk = synth.synth_batch(16, 96, 96, 3, 1, seed=900 + k)
+        batches.append((torch.from_numpy(img).cuda(), torch.from_numpy(msk).cuda()))
+    out = {}
+    for mode in (1, 3):
+        os.environ["NUNET_DP_MODE"] = str(mode)
+        torch.manual_seed(0)
+        m = nunet_amd.archs.NestedUNet(1, 3, False, dtype="bf16").cuda().train()
+        ts = TR.TrainStep(m, (16, 3, 96, 96), lr=1e-2)
+        assert ts.dp and ts.dp_mode == mode
+        stamps = torch.zeros(4, dtype=torch.int64, device="cuda")
+        snap = torch.zeros_like(ts._buckets[0])
+        calls = []
+        real = dist.all_reduce
+        if mode == 3:
+            # every exchange the step issues also leaves a device timestamp (and, for bucket 0, a snapshot) on the stream it was
+            # issued on: "when were this bucket's producers done" as seen from inside the graph
+            def spy(t, *a, **kw):
+                k = len(calls) % 2
+                calls.append(torch.cuda.current_stream().cuda_stream)
+                L.check(L.lib().nunet_debug_stamp(L.ptr(stamps, 8 * k), L.stream()), "stamp")
+                if k == 0:
+                    snap.copy_(t, non_blocking=True)
+                return real(t, *a, **kw)
+            TR.dist.all_reduce = spy
+        ts.capture(*batches[0])
+        if mode == 3:
+            TR.dist.all_reduce = real
+            assert ts.g_fb is not None and ts.g_opt is None           # the whole step, exchanges included, is ONE graph
+            assert len(calls) >= 2 and calls[-2] != calls[-1]         # bucket 0 went to a side stream, bucket 1 to the caller's
+        leads = []
+        for x, t in batches:
+            if mode == 3:
+                snap.zero_()
+            ts.step(x, t)
+            if mode == 3:
+                L.check(L.lib().nunet_debug_stamp(L.ptr(stamps, 16), L.stream()), "stamp")      # end of the step, caller's stream
+                torch.cuda.synchronize()
+                tk = stamps.tolist()
+                leads.append(((tk[2] - tk[0]) / 100e3, (tk[2] - tk[1]) / 100e3))       # ms: bucket-0-ready -> end, bucket-1-ready -> end
+                assert torch.equal(snap, ts._buckets[0]) and float(snap.abs().sum()) > 0   # world 1: the exchange is the identity
+        torch.cuda.synchronize()
+        out[mode] = (ts.eng.flat_params.clone().cpu(), ts.mom.clone().cpu(), ts.epoch_stats(), leads)
+        del ts, m
+    q.put((bool(torch.equal(out[1][0], out[3][0]) and torch.equal(out[1][1], out[3][1])), out[1][2], out[3][2], out[3][3]))
+    dist.destroy_process_group()
+
+
+def test_exchange_inside_the_step_graph_overlaps_phase_two():
+    """NUNET_DP_MODE=3: the data-parallel step is ONE graph that contains both gradient exchanges. Rehearsed with a single-rank
+    RCCL group (the collectives are real calls into torch.distributed, captured into the graph):
+      * it computes exactly what layout 1 computes (bit-identical parameters and momentum after three steps),
+      * the first bucket's exchange sits on a side branch that is released by its producing kernels, not by the end of the pass:
+        with a 2 ms spin kernel heading phase 2 (NUNET_DEBUG_SPIN_US) the bucket is ready - and bitwise final - more than 1 ms
+        before the step ends, while the second bucket is ready only at the end of the pass."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_in_graph_worker, args=(_free_port(), q))
+    p.start()
+    import queue
+    res = None
+    for _ in range(200):
+        try:
+            res = q.get(timeout=2)
+            break
+        except queue.Empty:
+            if p.exitcode not in (None, 0):
+                break
+    p.join(60)
+    assert res is not None and p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
+    same, s1, s3, leads = res
+    assert same, "layout 3 must compute what layout 1 computes"
+    assert s1 == s3 and np.isfinite(s1[0])
+    print("ms from bucket-ready to the end of the step (bucket 0, bucket 1):", leads)
+    assert min(l[0] for l in leads) > 1.0, leads          # bucket 0 was ready > 1 ms before the end (phase 2 + its 2 ms spin ran beside it)
+    assert max(l[1] for l in leads) < min(l[0] for l in leads)   # bucket 1 only after the whole pass
