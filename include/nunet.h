@@ -418,6 +418,28 @@ int nunet_graph_launch(nunet_graph* graph, nunet_stream_t stream);
 int nunet_graph_info(const nunet_graph* graph, int32_t* nodes, int32_t* edges_captured, int32_t* edges_final, int32_t* padding, int32_t* lanes);
 void nunet_graph_destroy(nunet_graph* graph);
 
+/* ------------------------------------------------------------------------ */
+/* Segmented step (csrc/graph.hip): the same captured step as a PROGRAM of    */
+/* single-stream graph segments on the plan's real streams, with the          */
+/* cross-lane dependencies as event records / waits between graph launches.   */
+/* ROCm 7.2 replays a hipGraph that has parallel branches node by node        */
+/* (2.6-5 us of launch + synchronisation per node) but a single-stream graph  */
+/* as one batch of pre-built packets (0.7 us per node); the step has ~160     */
+/* nodes, ~75 of them on its critical chain.                                   */
+/* Recording takes two passes over the same body (every launch made through   */
+/* this library on `stream` or on the plan's lanes between begin and end):    */
+/* dry = 1 launches nothing and finds the events that are waited on across     */
+/* streams; dry = 0 records. nunet_seg_end returns the program (NULL after a   */
+/* dry pass). The stream must outlive the program: it replays on it.           */
+/* ------------------------------------------------------------------------ */
+typedef struct nunet_seg nunet_seg;
+int nunet_seg_begin(nunet_stream_t stream, int32_t dry);
+int nunet_seg_end(nunet_stream_t stream, nunet_seg** out);
+/* replay, ordered after what the caller queued on `stream`; `stream` continues after the program's last segment */
+int nunet_seg_launch(nunet_seg* prog, nunet_stream_t stream);
+int nunet_seg_info(const nunet_seg* prog, int32_t* graph_launches, int32_t* event_records, int32_t* event_waits, int32_t* kernel_nodes);
+void nunet_seg_destroy(nunet_seg* prog);
+
 #ifdef __cplusplus
 }
 #endif

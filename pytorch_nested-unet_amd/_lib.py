@@ -167,6 +167,11 @@ _SIG = {
     "nunet_graph_launch": (_i32, [_vp, _vp]),
     "nunet_graph_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "nunet_graph_destroy": (None, [_vp]),
+    "nunet_seg_begin": (_i32, [_vp, _i32]),
+    "nunet_seg_end": (_i32, [_vp, C.POINTER(_vp)]),
+    "nunet_seg_launch": (_i32, [_vp, _vp]),
+    "nunet_seg_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "nunet_seg_destroy": (None, [_vp]),
     "nunet_plan_stamps_read": (_i32, [_vp, _i32, C.POINTER(C.c_uint64), _i32, C.POINTER(_i32), C.c_char_p, _i32]),
 }
 

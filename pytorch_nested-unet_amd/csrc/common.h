@@ -55,11 +55,15 @@ struct ProfScope {
   ProfScope(int cls, double flops, double bytes, hipStream_t) : on(g_prof_on) { if (on) nunet_prof_push(cls, flops, bytes); }
   ~ProfScope() { if (on) nunet_prof_pop(); }
 };
+// Segmented step recording (graph.hip, nunet_seg_*): while a DRY pass runs, launches are skipped - the pass only finds out which
+// events are waited on across lanes.
+extern thread_local bool g_dry_run;
 // Every kernel launch goes through this. Timing off: plain hipLaunchKernelGGL. Timing on (bench.py's roofline leg):
 // hipExtLaunchKernelGGL with a start/stop event pair, which carries the DISPATCH's own begin/end timestamps (what
 // rocprofv3 --kernel-trace reports) - events recorded around a launch as separate stream markers add ~5 us to a 15 us kernel.
 #define NUNET_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                    \
   do {                                                                                                          \
+    if (g_dry_run) break;                                                                                       \
     hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                                  \
     if (g_prof_on) nunet_prof_kernel_events(&pe0_, &pe1_);                                                      \
     if (pe0_) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, pe0_, pe1_, 0, __VA_ARGS__);            \
@@ -70,6 +74,20 @@ struct ProfScope {
 // captured into a hipGraph its memset node ran unordered w.r.t. the neighbouring kernel
 // nodes on replay (accumulators were cleared late / early), see DESIGN.md.
 int nunet_zero_async(void* p, size_t bytes, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// Segmented recording of a multi-lane step (graph.hip). ROCm 7.2 replays a hipGraph with parallel branches by enqueueing
+// node after node with a synchronisation of its own (2.6-5 us per node, tools/graph_gap_probe.py), while a single-stream
+// graph replays as one batch of pre-built packets (0.7 us per node). So the plan's lanes are NOT captured as branches of one
+// graph: every lane keeps a real stream, its ops are captured into single-stream graph SEGMENTS, and the cross-lane
+// dependencies become event records / waits between the graph launches. The lane scheduler (plan.hip, Sched) routes its
+// stream waits, event records and "about to launch on this stream" through these hooks; they return false when no
+// recording is active (the caller then does the real HIP call).
+// ---------------------------------------------------------------------------
+bool seg_active();
+bool seg_wait(hipStream_t st, hipEvent_t ev);      // `st` must wait for `ev` (recorded on another stream)
+bool seg_record(hipEvent_t ev, hipStream_t st);    // `ev` marks the current tail of `st`
+void seg_touch(hipStream_t st);                    // kernels are about to be launched on `st`
 
 static inline int dtype_size(int dt) { return dt == NUNET_F32 ? 4 : 2; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -904,6 +904,7 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   long per_cu = (long)(160 * 1024 / lds_bytes);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2048 / C::NT) per_cu = 2048 / C::NT;
+  { static int cap = -1; if (cap < 0) { const char* e = getenv("NUNET_CONV_PER_CU"); cap = e ? atoi(e) : 0; } if (cap > 0 && per_cu > cap) per_cu = cap; }
   const long resident = 256 * per_cu;
   const long rounds = (items + resident - 1) / resident;
   const long grid = (items + rounds - 1) / rounds;

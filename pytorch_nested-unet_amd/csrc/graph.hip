@@ -202,3 +202,159 @@ extern "C" void nunet_graph_destroy(nunet_graph* G) {
   if (G->launch_stream) (void)hipStreamDestroy(G->launch_stream);
   delete G;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Segmented step (see common.h): a recorded program of {launch single-stream graph, record event, wait event} over real
+// streams. Recording takes two passes of the same step body:
+//   dry  - nothing is launched (g_dry_run); every cross-stream wait the lane scheduler asks for marks its event as NEEDED;
+//   real - streams capture lazily (the first launch after a cut begins a capture on that stream); a cross-stream wait or the
+//          record of a NEEDED event cuts the stream's open segment (end capture, instantiate, emit its launch) and is emitted
+//          as an instruction; records of events nobody waits on across streams are dropped (same-stream order is implicit).
+// ---------------------------------------------------------------------------------------------------------
+thread_local bool g_dry_run = false;
+
+namespace {
+struct SegInstr { int op; hipStream_t st; hipEvent_t ev; hipGraphExec_t exec; };   // op 0 launch, 1 record, 2 wait
+struct SegRec {
+  bool dry = false;
+  hipStream_t main = nullptr;
+  std::vector<hipEvent_t> needed;            // sorted after the dry pass
+  std::vector<hipStream_t> capturing;        // streams with an open segment
+  std::vector<SegInstr> prog;
+  std::vector<hipGraph_t> graphs;
+  std::vector<hipGraphExec_t> execs;
+  bool failed = false;
+  char err[160] = {0};
+  bool is_cap(hipStream_t st) const { return std::find(capturing.begin(), capturing.end(), st) != capturing.end(); }
+  bool is_needed(hipEvent_t e) const { return std::binary_search(needed.begin(), needed.end(), e); }
+  void fail(const char* what, hipError_t e) { if (!failed) { failed = true; snprintf(err, sizeof(err), "%s: %s", what, hipGetErrorString(e)); } (void)hipGetLastError(); }
+  void cut(hipStream_t st) {
+    auto it = std::find(capturing.begin(), capturing.end(), st);
+    if (it == capturing.end()) return;
+    capturing.erase(it);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (e != hipSuccess || !g) { fail("segment end capture", e); return; }
+    size_t n = 0;
+    (void)hipGraphGetNodes(g, nullptr, &n);
+    if (n == 0) { (void)hipGraphDestroy(g); return; }          // nothing was launched since the cut
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { fail("segment instantiate", e); (void)hipGraphDestroy(g); return; }
+    graphs.push_back(g); execs.push_back(x);
+    prog.push_back(SegInstr{0, st, nullptr, x});
+  }
+  void touch(hipStream_t st) {
+    if (dry || is_cap(st)) return;
+    const hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { fail("segment begin capture", e); return; }
+    capturing.push_back(st);
+  }
+};
+thread_local SegRec* g_seg = nullptr;
+thread_local std::vector<hipEvent_t> g_seg_needed;      // result of the last dry pass
+}  // namespace
+
+struct nunet_seg {
+  std::vector<SegInstr> prog;
+  std::vector<hipGraph_t> graphs;
+  std::vector<hipGraphExec_t> execs;
+  hipStream_t main;
+  hipEvent_t ev_in, ev_out;
+  int n_launch, n_record, n_wait, n_nodes;
+};
+
+bool seg_active() { return g_seg != nullptr; }
+bool seg_wait(hipStream_t st, hipEvent_t ev) {
+  SegRec* r = g_seg;
+  if (!r) return false;
+  if (r->dry) { r->needed.push_back(ev); return true; }
+  r->cut(st);
+  r->prog.push_back(SegInstr{2, st, ev, nullptr});
+  return true;
+}
+bool seg_record(hipEvent_t ev, hipStream_t st) {
+  SegRec* r = g_seg;
+  if (!r) return false;
+  if (r->dry || !r->is_needed(ev)) return true;
+  r->cut(st);
+  r->prog.push_back(SegInstr{1, st, ev, nullptr});
+  return true;
+}
+void seg_touch(hipStream_t st) { if (g_seg) g_seg->touch(st); }
+
+extern "C" int nunet_seg_begin(nunet_stream_t s, int32_t dry) {
+  NUNET_REQUIRE(s, "seg_begin: recording needs an explicit (non-default) stream");
+  NUNET_REQUIRE(!g_seg && !g_cap.active, "seg_begin: a recording / capture is already active on this thread");
+  SegRec* r = new SegRec();
+  r->dry = dry != 0; r->main = (hipStream_t)s;
+  if (!r->dry) { r->needed = g_seg_needed; std::sort(r->needed.begin(), r->needed.end()); }
+  g_seg = r;
+  g_dry_run = r->dry;
+  r->touch(r->main);            // launches the caller makes on its own stream belong to the program too
+  if (r->failed) { nunet_set_error("seg_begin: %s", r->err); g_seg = nullptr; g_dry_run = false; delete r; return NUNET_ELAUNCH; }
+  return NUNET_OK;
+}
+
+extern "C" void nunet_seg_destroy(nunet_seg* G);
+extern "C" int nunet_seg_end(nunet_stream_t s, nunet_seg** out) {
+  SegRec* r = g_seg;
+  NUNET_REQUIRE(r && r->main == (hipStream_t)s, "seg_end: no recording active on this stream");
+  g_seg = nullptr; g_dry_run = false;
+  if (r->dry) {
+    g_seg_needed = r->needed;
+    delete r;
+    if (out) *out = nullptr;
+    return NUNET_OK;
+  }
+  while (!r->capturing.empty()) r->cut(r->capturing.back());
+  nunet_seg* G = new nunet_seg();
+  G->prog = r->prog; G->graphs = r->graphs; G->execs = r->execs; G->main = r->main; G->ev_in = G->ev_out = nullptr;
+  G->n_launch = G->n_record = G->n_wait = G->n_nodes = 0;
+  for (const SegInstr& i : G->prog) { if (i.op == 0) ++G->n_launch; else if (i.op == 1) ++G->n_record; else ++G->n_wait; }
+  for (hipGraph_t g : G->graphs) { size_t n = 0; (void)hipGraphGetNodes(g, nullptr, &n); G->n_nodes += (int)n; }
+  const bool failed = r->failed;
+  if (failed) nunet_set_error("seg_end: %s", r->err);
+  delete r;
+  if (failed || !out || hipEventCreateWithFlags(&G->ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&G->ev_out, hipEventDisableTiming) != hipSuccess) {
+    if (!failed) nunet_set_error("seg_end: cannot create the hand-over events");
+    nunet_seg_destroy(G);
+    return NUNET_ELAUNCH;
+  }
+  *out = G;
+  return NUNET_OK;
+}
+
+// Replay: the recorded program on its own streams, ordered after what the caller queued on `s`; `s` continues after it.
+extern "C" int nunet_seg_launch(nunet_seg* G, nunet_stream_t s) {
+  NUNET_REQUIRE(G, "seg_launch: null program");
+  hipStream_t cs = (hipStream_t)s;
+  hipError_t e = hipSuccess;
+  if (cs != G->main) { e = hipEventRecord(G->ev_in, cs); if (e == hipSuccess) e = hipStreamWaitEvent(G->main, G->ev_in, 0); }
+  for (size_t k = 0; k < G->prog.size() && e == hipSuccess; ++k) {
+    const SegInstr& i = G->prog[k];
+    if (i.op == 0) e = hipGraphLaunch(i.exec, i.st);
+    else if (i.op == 1) e = hipEventRecord(i.ev, i.st);
+    else e = hipStreamWaitEvent(i.st, i.ev, 0);
+  }
+  if (e == hipSuccess && cs != G->main) { e = hipEventRecord(G->ev_out, G->main); if (e == hipSuccess) e = hipStreamWaitEvent(cs, G->ev_out, 0); }
+  if (e != hipSuccess) { nunet_set_error("seg_launch: %s", hipGetErrorString(e)); (void)hipGetLastError(); return NUNET_ELAUNCH; }
+  return NUNET_OK;
+}
+
+extern "C" int nunet_seg_info(const nunet_seg* G, int32_t* launches, int32_t* records, int32_t* waits, int32_t* kernel_nodes) {
+  NUNET_REQUIRE(G && launches && records && waits && kernel_nodes, "seg_info: null pointer");
+  *launches = G->n_launch; *records = G->n_record; *waits = G->n_wait; *kernel_nodes = G->n_nodes;
+  return NUNET_OK;
+}
+
+extern "C" void nunet_seg_destroy(nunet_seg* G) {
+  if (!G) return;
+  for (hipGraphExec_t x : G->execs) (void)hipGraphExecDestroy(x);
+  for (hipGraph_t g : G->graphs) (void)hipGraphDestroy(g);
+  if (G->ev_in) (void)hipEventDestroy(G->ev_in);
+  if (G->ev_out) (void)hipEventDestroy(G->ev_out);
+  delete G;
+}

@@ -456,6 +456,8 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   unsigned long long* stamps;              // device, [2][STAMP_CAP]
   hipEvent_t b0_event;                     // recorded when the first gradient bucket (phase-1 nodes + heads) is complete
   bool b0_enabled;
+  int seg_lanes_distinct;                  // how many of them were measured to run beside the caller's stream and each other
+  hipStream_t seg_lanes[3];                // side-lane streams of the segmented recording (created together: distinct hardware queues)
   struct Sched* open_sched;                // backward pass left open after phase 1 (nunet_plan_backward_phase bit 3): lanes, dependency state
   std::vector<hipEvent_t> b0_events;       // ... and the last-writer events of the first bucket's gradients, for nunet_plan_bucket0_wait
   std::vector<std::string> stamp_labels[2];
@@ -681,6 +683,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->cap_next = 0;
   rt->stamps = nullptr;
   rt->b0_event = nullptr; rt->b0_enabled = false; rt->open_sched = nullptr;
+  rt->seg_lanes[0] = rt->seg_lanes[1] = rt->seg_lanes[2] = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
   { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
   for (int l = 0; l < NLANES; ++l) {
@@ -702,6 +705,11 @@ extern "C" void nunet_plan_destroy(nunet_plan* p) {
     if (!p->rt->lanes_external)
       for (int l = 0; l < NLANES; ++l) if (p->rt->lanes[l]) (void)hipStreamDestroy(p->rt->lanes[l]);
     for (size_t k = 0; k < p->rt->cap_streams.size(); ++k) (void)hipStreamDestroy(p->rt->cap_streams[k]);
+    for (int q = 0; q < 3; ++q) {
+      bool dup = false;
+      for (int r = 0; r < q; ++r) dup |= p->rt->seg_lanes[r] == p->rt->seg_lanes[q];
+      if (p->rt->seg_lanes[q] && !dup && p->rt->seg_lanes[q] != p->rt->lanes[q + 1]) (void)hipStreamDestroy(p->rt->seg_lanes[q]);
+    }
     for (int q = 0; q < 2; ++q)
       for (size_t k = 0; k < p->rt->events[q].size(); ++k) (void)hipEventDestroy(p->rt->events[q][k]);
     if (p->rt->stamps) (void)hipFree(p->rt->stamps);
@@ -808,6 +816,9 @@ struct Sched {
     for (int x : wr) if (x >= 0) { if (nw < 16) w[nw++] = x; else failed = true; }
     return begin_v(lane_map[lane], r, nr, w, nw);
   }
+  // stream waits / event records: real HIP calls, or instructions of the segmented program being recorded (graph.hip)
+  static void wait_on(hipStream_t st, hipEvent_t ev) { if (!seg_wait(st, ev)) (void)hipStreamWaitEvent(st, ev, 0); }
+  static void record_on(hipEvent_t ev, hipStream_t st) { if (!seg_record(ev, st)) (void)hipEventRecord(ev, st); }
   hipStream_t begin_v(int lane, const int* rd, int nrd, const int* wr, int nwr) {   // `lane` already mapped
     if (!multi) return main_s;
     cur_lane = lane; nreads = 0; nwrites = 0; npend = 0;
@@ -835,9 +846,10 @@ struct Sched {
       }
     } else if (!used[lane]) {
       used[lane] = true;
-      (void)hipStreamWaitEvent(st, fork_ev, 0);
+      if (st != main_s) wait_on(st, fork_ev);
     }
-    for (int k = 0; k < npend; ++k) (void)hipStreamWaitEvent(st, pend[k], 0);
+    for (int k = 0; k < npend; ++k) wait_on(st, pend[k]);
+    seg_touch(st);                       // (segmented recording: the op's launches open / continue this stream's segment)
     return st;
   }
 
@@ -867,7 +879,7 @@ struct Sched {
     stamp(st, cur_lane); cur_name[0] = 0;
     if (capturing) graph_tag_tail(st, cur_lane);
     hipEvent_t ev = new_event();
-    (void)hipEventRecord(ev, st);
+    record_on(ev, st);
     lane_tail[cur_lane] = ev;
     for (int k = 0; k < nreads; ++k) { res[reads[k]].r_ev[cur_lane] = ev; res[reads[k]].r_st[cur_lane] = st; }
     for (int k = 0; k < nwrites; ++k) {
@@ -879,11 +891,51 @@ struct Sched {
   void join() {
     if (!multi) return;
     for (int l = 0; l < NLANES; ++l)
-      if (used[l] && lane_tail[l]) (void)hipStreamWaitEvent(main_s, lane_tail[l], 0);
+      if (used[l] && lane_tail[l] && lane_s[l] != main_s) wait_on(main_s, lane_tail[l]);
+    seg_touch(main_s);                   // what the caller launches next on its stream opens a new segment
   }
 };
 
 static void sched_free(Sched* s) { delete s; }
+
+// Side-lane streams of the segmented program. ROCm maps every stream onto one of 4 hardware queues at creation and offers no way
+// to ask which (tools/seg_overlap_probe.py: of 8 fresh streams some pairs share a queue, and two lanes that share a queue run
+// strictly one after the other). So the lanes are CHOSEN BY MEASUREMENT: a 100 us single-workgroup spin kernel on two streams at
+// once takes 100 us when they sit on different queues and 200 us when not. Three candidates that overlap with the caller's
+// stream and with each other become lanes 1-3 (the rest are destroyed). Called outside any capture, once per plan.
+int nunet_debug_spin(int32_t us, int32_t tag, nunet_stream_t s);
+static void seg_pick_lanes(PlanRt* rt, hipStream_t main_s) {
+  const int NC = 12, SPIN_US = 100;
+  hipStream_t cand[NC];
+  int nc = 0;
+  for (int k = 0; k < NC; ++k) if (hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking) == hipSuccess) ++nc; else (void)hipGetLastError();
+  hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+  auto overlap = [&](hipStream_t a, hipStream_t b) {          // true: a and b run side by side
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    (void)hipEventRecord(e0, a);
+    (void)nunet_debug_spin(SPIN_US, 1, a);
+    (void)nunet_debug_spin(SPIN_US, 1, b);
+    (void)hipEventRecord(eb, b);
+    (void)hipStreamWaitEvent(a, eb, 0);
+    (void)hipEventRecord(e1, a);
+    (void)hipStreamSynchronize(a);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return ms * 1000.f < 1.5f * SPIN_US;
+  };
+  hipStream_t pick[3]; int np = 0;
+  bool usedc[NC] = {false};
+  for (int k = 0; k < nc && np < 3; ++k) {
+    bool ok = overlap(main_s, cand[k]);
+    for (int q = 0; q < np && ok; ++q) ok = overlap(pick[q], cand[k]);
+    if (ok) { pick[np++] = cand[k]; usedc[k] = true; }
+  }
+  for (int k = 0; k < nc; ++k) if (!usedc[k]) (void)hipStreamDestroy(cand[k]);
+  for (int q = 0; q < 3; ++q) rt->seg_lanes[q] = q < np ? pick[q] : (np > 0 ? pick[q % np] : rt->lanes[q + 1]);
+  rt->seg_lanes_distinct = np;
+  if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (eb) (void)hipEventDestroy(eb);
+}
 
 void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
   const int pass = pass_;
@@ -914,6 +966,7 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) capturing = true;
     else (void)hipGetLastError();
+    if (seg_active()) capturing = false;   // segmented recording: fixed lanes on real streams (the caller's stream is merely inside a segment)
     if (!capturing && rt->cap_streams.empty()) {
       // pool for later captures, created outside any capture (warm-up passes run eagerly first)
       for (int k = 0; k < 320; ++k) {
@@ -929,9 +982,23 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
   // block's lane (measured best on MI355X: separate weight-gradient lanes add cross-queue edges that cost more than the
   // overlap they buy; the exception is the deferral of the shallow chain blocks' weight gradients, see the backward pass)
   for (int l = 0; l < NLANES; ++l) { lane_map[l] = l % 5; lane_s[l] = capturing ? nullptr : rt->lanes[l]; used[l] = false; lane_tail[l] = nullptr; }
+  if (multi && seg_active()) {
+    // four real streams = ROCm's four hardware queues: the critical chain (lane 0) runs on the caller's stream itself - no
+    // fork / join edge on the chain -, the side lanes on three streams of the plan's, the deferred weight gradients share lane 3's
+    lane_s[0] = main_s; used[0] = true;
+    if (!rt->seg_lanes[0]) {
+      // (the dry pass of a recording comes first and captures nothing: the only moment the calibration kernels may run on `s`)
+      hipStreamCaptureStatus cs2 = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(main_s, &cs2);
+      if (cs2 != hipStreamCaptureStatusActive) { const bool keep = g_dry_run; g_dry_run = false; seg_pick_lanes(rt, main_s); g_dry_run = keep; }
+      else for (int q = 0; q < 3; ++q) rt->seg_lanes[q] = rt->lanes[q + 1];
+    }
+    for (int q = 0; q < 3; ++q) lane_s[q + 1] = rt->seg_lanes[q];
+    lane_s[4] = lane_s[3];
+  }
   if (multi) {
     fork_ev = new_event();
-    (void)hipEventRecord(fork_ev, main_s);
+    record_on(fork_ev, main_s);
     if (capturing) graph_tag_tail(main_s, -1);   // launches made so far on the caller's stream are not ours to place
   }
 }

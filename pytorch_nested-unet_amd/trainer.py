@@ -321,8 +321,12 @@ class TrainStep:
         if self.dp and self.dp_mode == 3 and dist.get_backend(self.pg) == "gloo":
             self.dp_mode = 1                                # a host-side exchange cannot be a graph node
         if not self.dp:
-            # the whole step as ONE hipGraph (csrc/graph.hip), captured on a side stream, replayed on the caller's
-            self.g_fb = _NativeGraph(s, lambda: (self._fwd_bwd(), self._opt()))
+            # the whole step, recorded once on a side stream and replayed on the caller's: as ONE multi-branch hipGraph (default), or
+            # - NUNET_SEGMENTED=1 - as a program of single-stream graph segments over the plan's lanes with the cross-lane
+            # dependencies as events between graph launches (csrc/graph.hip nunet_seg_*: explicit node -> queue placement on lanes
+            # chosen by measurement; 2.56 vs 1.91 ms per step on MI355X: every segment launch costs ~10 us on its lane)
+            body = lambda: (self._fwd_bwd(), self._opt())
+            self.g_fb = _SegProgram(s, body) if os.environ.get("NUNET_SEGMENTED", "0") == "1" else _NativeGraph(s, body)
         else:
             if self.dp_auto:
                 self._choose_layout(s)
@@ -452,6 +456,44 @@ class TrainStep:
         k = max(self.steps, 1)
         m = self.meters.tolist()
         return m[0] / k, m[1] / k
+
+
+class _SegProgram:
+    """nunet_seg_* wrapper with the replay() surface of torch.cuda.CUDAGraph: the step body is run twice on `side_stream` - a dry
+    pass that launches nothing and finds the cross-lane events, then the recording pass."""
+
+    def __init__(self, side_stream, body):
+        import ctypes as C
+        lib = L.lib()
+        self.stream = side_stream            # the program replays on this stream: keep it alive
+        self.handle = None
+        with torch.cuda.stream(side_stream):
+            for dry in (1, 0):
+                L.check(lib.nunet_seg_begin(L.stream(), dry), "seg_begin")
+                try:
+                    body()
+                finally:
+                    h = C.c_void_p()
+                    rc = lib.nunet_seg_end(L.stream(), C.byref(h))
+                L.check(rc, "seg_end")
+        self.handle = h
+
+    def info(self):
+        import ctypes as C
+        v = [C.c_int32() for _ in range(4)]
+        L.check(L.lib().nunet_seg_info(self.handle, *[C.byref(x) for x in v]), "seg_info")
+        return dict(zip(("graph_launches", "event_records", "event_waits", "kernel_nodes"), (x.value for x in v)))
+
+    def replay(self):
+        L.check(L.lib().nunet_seg_launch(self.handle, L.stream()), "seg_launch")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                L.lib().nunet_seg_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class _NativeGraph:

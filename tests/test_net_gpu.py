@@ -701,3 +701,39 @@ def test_step_from_decoded_uint8_batches(dtype, synth):
     img, msk = synth.synth_blob_pairs(3 * n, hw, hw, seed=77)
     np.testing.assert_allclose(D.preprocess_images(raw[:n]).cpu().numpy(), img[:n], atol=2e-7, rtol=2e-5)
     assert np.array_equal(D.preprocess_masks(m8[:n]).cpu().numpy(), msk[:n])
+
+
+def test_segmented_step_program_equals_the_single_graph(synth):
+    """The step recorded as a program of single-stream graph segments over the plan's lanes (NUNET_SEGMENTED=1: nunet_seg_*, cross-lane
+    dependencies as event records / waits between graph launches on streams chosen by measurement) computes exactly what the
+    one multi-branch hipGraph computes: bit-identical parameters, momentum and BatchNorm buffers after three steps. (A dropped
+    dependency would show as a race here: the program keeps only the event records some other lane waits on.)"""
+    import os
+    from nunet_amd.trainer import TrainStep, _SegProgram
+    n, hw = 16, 96
+    torch.manual_seed(11)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, True).state_dict().items()}
+    batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=300 + k) for k in range(3)]
+    outs = []
+    for seg in ("0", "1"):
+        os.environ["NUNET_SEGMENTED"] = seg
+        try:
+            m = nunet_amd.archs.NestedUNet(1, 3, True, dtype="bf16")
+            m.load_state_dict(sd)
+            m = m.to(DEV).train()
+            ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2)
+            ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+        finally:
+            os.environ.pop("NUNET_SEGMENTED", None)
+        assert isinstance(ts.g_fb, _SegProgram) == (seg == "1")
+        if seg == "1":
+            info = ts.g_fb.info()
+            print("segmented program:", info)
+            assert info["graph_launches"] > 4 and info["event_waits"] >= info["event_records"] > 0 and info["kernel_nodes"] > 100
+        for img, msk in batches:
+            ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (ts.eng.flat_params, ts.mom, ts.eng.bnbuf, ts.loss_out)])
+        del ts, m
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
