@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #define WAVE 64
+#define CONV_GROUP_MAX 4      // independent 3x3 convolutions one launch may carry (conv3x3.hip ConvGroup, plan.hip Sched::run_wave)
 
 // ---------------------------------------------------------------------------
 // error plumbing

@@ -203,9 +203,33 @@ static inline int conv_coef_floats(int lt, int cin, bool bnr, int cout) { return
 // Staging is branch-free: C0 and C1 are multiples of the chunk width, so the address of every staging unit is
 // fixed for an item up to the chunk's (uniform) channel offset: pointers are set up once per item, a pixel
 // outside the image points at a page of zeros, and a chunk's staging is 12 plain 16-byte loads.
+// A launch carries up to CONV_GROUP_MAX independent problems of one kernel variant (same tile configuration, same fused
+// BatchNorm work): the plan's single-stream schedule groups ready convolutions of different blocks of the x_{i,j} grid, whose
+// workgroups then overlap each other's load / compute / store phases (two such launches side by side cost 1.3-1.4 x one,
+// tools/conv_concurrency_probe.py). Workgroups are dealt to the problems round-robin (problem k owns `grid[k]` of them, sorted
+// ascending), so all problems start together instead of one after the other.
+struct ConvGroup { int n; int grid[CONV_GROUP_MAX]; ConvP p[CONV_GROUP_MAX]; };
+__device__ __forceinline__ void conv_group_decode(const ConvGroup& g, int b, int& k, int& v) {
+  int base = 0, prevg = 0, live = g.n;
+  k = 0; v = b;
+#pragma unroll
+  for (int j = 0; j < CONV_GROUP_MAX; ++j) {
+    if (j < g.n) {
+      const int span = (g.grid[j] - prevg) * live;
+      if (b >= base && b < base + span) { const int r = b - base; const int q = r / live; k = j + (r - q * live); v = prevg + q; }
+      base += span; prevg = g.grid[j]; --live;
+    }
+  }
+}
+
 template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR, int LT>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvGroup grp) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
+  int gk = 0, vbid = (int)blockIdx.x;
+  if (grp.n > 1) conv_group_decode(grp, (int)blockIdx.x, gk, vbid);
+  gk = __builtin_amdgcn_readfirstlane(gk); vbid = __builtin_amdgcn_readfirstlane(vbid);
+  const ConvP& p = grp.p[gk];
+  const int vgrid = grp.grid[gk];
   typedef Mma<T> M;
   constexpr int PS = C::PS, EPV = C::EPV, BN = C::BN, BM = C::BM, NT = C::NT, KS = C::KS, OS = C::OS;
 
@@ -589,7 +613,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         float sum = 0.f;
 #pragma unroll
         for (int wv = 0; wv < WM * WN; ++wv) sum += s_bn[(wv * 2 + vsel) * BN + c];
-        if (!(NUNET_ABLATE & 32)) fx_add(p.bn_sums + ((size_t)((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum); else asm volatile("" :: "v"(sum));
+        if (!(NUNET_ABLATE & 32)) fx_add(p.bn_sums + ((size_t)((vbid & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum); else asm volatile("" :: "v"(sum));
       }
     }
     if (p.stats) {
@@ -598,11 +622,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < WM; ++k) sum += s_red[(k * BN + c) * 2 + vsel];
-        if (!(NUNET_ABLATE & 32)) fx_add(p.stats + ((size_t)((blockIdx.x & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum); else asm volatile("" :: "v"(sum));
+        if (!(NUNET_ABLATE & 32)) fx_add(p.stats + ((size_t)((vbid & (bn_sum_replicas(p.Cout) - 1)) * 2 + vsel) * p.Cout + cur.co0 + c) * NUNET_FX_WORDS, sum); else asm volatile("" :: "v"(sum));
       }
     }
   };
-  int item = blockIdx.x;
+  int item = vbid;
   if (item >= p.nItems) return;
   Item cur = decode(item);
   set_hgp(cur);
@@ -632,7 +656,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       bn_stat_coeffs(a, c, mean, invstd, var, mf);
       const float sc = p.tf_gamma[c] * invstd;
       s_coef[c] = sc; s_coef[p.Cin + c] = __builtin_fmaf(-mean, sc, p.tf_beta[c]);
-      if (blockIdx.x == 0 && p.tf_training) {
+      if (vbid == 0 && p.tf_training) {
         if (p.tf_save) { p.tf_save[c] = mean; p.tf_save[p.Cin + c] = invstd; }
         if (p.tf_rm) {
           const float unb = p.M > 1.f ? var * (p.M / (p.M - 1.f)) : var;
@@ -641,7 +665,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
         }
       }
     }
-    if (blockIdx.x == 0 && p.tf_training && tid == 0 && p.tf_nbt) *p.tf_nbt += 1;
+    if (vbid == 0 && p.tf_training && tid == 0 && p.tf_nbt) *p.tf_nbt += 1;
   }
   if constexpr (LT == 2) {
     const int nrep = bn_sum_replicas(p.Cin);
@@ -653,7 +677,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
       float A, B;
       bn_bwd_AB(mean, istd, sc, (float)(t1 / (double)p.M), (float)(t2 / (double)p.M), A, B);
       s_coef[c] = sc; s_coef[p.Cin + c] = __builtin_fmaf(-mean, sc, p.tf_beta[c]); s_coef[2 * p.Cin + c] = A; s_coef[3 * p.Cin + c] = B;
-      if (blockIdx.x == 0) {
+      if (vbid == 0) {
         // d beta = sum dz, d gamma = sum dz * xhat; the conv bias in front of a BatchNorm has gradient sum(dy) == 0
         if (p.tf_dbeta) p.tf_dbeta[c] = (float)t1;
         if (p.tf_dgamma) p.tf_dgamma[c] = (float)t2;
@@ -666,7 +690,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
   while (true) {
     __syncthreads();  // previous chunk's fragment reads / previous item's epilogue reads are done
     KSTAMP(kst); ++kst;       // a: barrier passed
-    if (!(NUNET_ABLATE & 8) || (item == (int)blockIdx.x && first_chunk)) write_lds(kb, LT != 0 && p.tf_store != nullptr && cur.co0 == 0);
+    if (!(NUNET_ABLATE & 8) || (item == vbid && first_chunk)) write_lds(kb, LT != 0 && p.tf_store != nullptr && cur.co0 == 0);
     KSTAMP(kst); ++kst;       // b: loads arrived, transformed, written to LDS
     if (first_chunk) {
       for (int m = tid; m < BM; m += NT) {
@@ -689,7 +713,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvP p) {
     if constexpr (SK) last_chunk = ncc >= c_hi; else last_chunk = nkb >= p.Cin;
     if (last_chunk) {
       nkb = 0;
-      nitem = item + gridDim.x;
+      nitem = item + vgrid;
       if (nitem < p.nItems) {
         nxt = decode(nitem); set_hgp(nxt); set_ptrs(nxt);
         if constexpr (SK) { ncc = nxt.ks * p.nch / p.S; nc_hi = (nxt.ks + 1) * p.nch / p.S; }
@@ -850,17 +874,19 @@ TileGeom nunet_choose_tile(int N, int H, int W, int BM, int HPMAX) {
 }
 
 template <typename T, int WM, int WN, int SM, int SN, bool SK, bool BNR>
-static void launch_conv_lt(int lt, unsigned grid, size_t dyn, hipStream_t st, const ConvP& p) {
+static void launch_conv_lt(int lt, unsigned grid, size_t dyn, hipStream_t st, const ConvGroup& g) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
-  if (lt == 1) NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 1>), dim3(grid), dim3(C::NT), dyn, st, p);
-  else if (lt == 2) NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 2>), dim3(grid), dim3(C::NT), dyn, st, p);
-  else NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 0>), dim3(grid), dim3(C::NT), dyn, st, p);
+  if (lt == 1) NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 1>), dim3(grid), dim3(C::NT), dyn, st, g);
+  else if (lt == 2) NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 2>), dim3(grid), dim3(C::NT), dyn, st, g);
+  else NUNET_LAUNCH((conv3x3_kernel<T, WM, WN, SM, SN, SK, BNR, 0>), dim3(grid), dim3(C::NT), dyn, st, g);
 }
 
+// everything a launch of one problem needs, for one tile configuration
+struct ConvSetup { ConvP p; long grid; size_t dyn; bool bnr; int lt; double flops, bytes; };
 template <typename T, int WM, int WN, int SM, int SN>
-static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
+static void conv_setup(const nunet_conv_desc* d, ConvSetup& S) {
   typedef ConvCfg<T, WM, WN, SM, SN> C;
-  ConvP p;
+  ConvP& p = S.p;
   p.src0 = d->src0; p.src1 = d->src1; p.C0 = d->C0; p.C1 = d->C1; p.P0 = d->P0; p.P1 = d->P1;
   p.w = d->wpack; p.bias = d->bias;
   p.dst0 = d->dst0; p.dst1 = d->dst1; p.D0 = d->D0; p.D1 = d->D1; p.Q0 = d->Q0; p.Q1 = d->Q1;
@@ -887,33 +913,46 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
   p.nch = p.nch0 + p.C1 / C::KC;
   // (measured on the 96x96 workload, tools/conv_layers.py: below ~60 items a split pays for its finalize launch, above it does not)
   if (d->splitk_ws && items <= 60 && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
-    int S = (int)((320 + items - 1) / items);
-    if (S > p.nch / 2) S = p.nch / 2;
-    const long long need = (long long)S * d->N * d->H * d->W * p.Cout;
-    if (S > 1 && need <= d->splitk_ws_floats) {
-      p.S = S; p.slabs = d->splitk_ws; p.slab_stride = (long long)d->N * d->H * d->W * p.Cout;
-      items *= S;
+    int Sn = (int)((320 + items - 1) / items);
+    if (Sn > p.nch / 2) Sn = p.nch / 2;
+    const long long need = (long long)Sn * d->N * d->H * d->W * p.Cout;
+    if (Sn > 1 && need <= d->splitk_ws_floats) {
+      p.S = Sn; p.slabs = d->splitk_ws; p.slab_stride = (long long)d->N * d->H * d->W * p.Cout;
+      items *= Sn;
     }
   }
   p.nItems = (int)items;
   p.invS = fastdiv_inv(p.S); p.invCoT = fastdiv_inv(p.nCoT); p.invTX = fastdiv_inv(p.tilesX); p.invTY = fastdiv_inv(p.tilesY);
   p.invTHW = fastdiv_inv(g.TH * g.TW); p.invTW = fastdiv_inv(g.TW); p.invHH2HW2 = fastdiv_inv((g.TH + 2) * (g.TW + 2)); p.invHW2 = fastdiv_inv(g.TW + 2);
   // persistent grid: resident workgroups only, item counts balanced across them
-  const size_t dyn = sizeof(float) * (size_t)conv_coef_floats(lt, p.Cin, bnr && p.S == 1, p.Cout);
-  const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN + dyn;
+  S.bnr = bnr; S.lt = lt;
+  S.dyn = sizeof(float) * (size_t)conv_coef_floats(lt, p.Cin, bnr && p.S == 1, p.Cout);
+  const size_t lds_bytes = sizeof(T) * C::STAGE_ELEMS + 4 * (3 * C::BM + C::HPMAX) + 8 * WM * C::BN + S.dyn;
   long per_cu = (long)(160 * 1024 / lds_bytes);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2048 / C::NT) per_cu = 2048 / C::NT;
-  { static int cap = -1; if (cap < 0) { const char* e = getenv("NUNET_CONV_PER_CU"); cap = e ? atoi(e) : 0; } if (cap > 0 && per_cu > cap) per_cu = cap; }
   const long resident = 256 * per_cu;
   const long rounds = (items + resident - 1) / resident;
-  const long grid = (items + rounds - 1) / rounds;
+  S.grid = (items + rounds - 1) / rounds;
   const double px = (double)d->N * d->H * d->W;
   const int acin = g_prof_alg_cin > 0 ? g_prof_alg_cin : p.Cin;
-  ProfScope ps(C::BN == 64 ? PC_CONV_M128N64 : C::BM == 256 ? PC_CONV_M256N32 : PC_CONV_M128N32, 2.0 * 9 * acin * p.Cout * px,
-               (px * (acin * (lt == 2 ? 2 : 1) + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T), st);
-  if (p.S > 1) {
-    launch_conv_lt<T, WM, WN, SM, SN, true, false>(lt, (unsigned)grid, dyn, st, p);
+  S.flops = 2.0 * 9 * acin * p.Cout * px;
+  S.bytes = (px * (acin * (lt == 2 ? 2 : 1) + p.Cout) + 9.0 * acin * p.Cout) * sizeof(T);
+}
+
+template <typename T, int WM, int WN, int SM, int SN>
+static int launch_conv_cfg(const nunet_conv_desc* const* ds, int n, hipStream_t st) {
+  typedef ConvCfg<T, WM, WN, SM, SN> C;
+  ConvSetup S[CONV_GROUP_MAX];
+  for (int k = 0; k < n; ++k) conv_setup<T, WM, WN, SM, SN>(ds[k], S[k]);
+  const int cls = C::BN == 64 ? PC_CONV_M128N64 : C::BM == 256 ? PC_CONV_M256N32 : PC_CONV_M128N32;
+  if (n == 1 && S[0].p.S > 1) {
+    const ConvSetup& s0 = S[0];
+    const ConvP& p = s0.p;
+    const nunet_conv_desc* d = ds[0];
+    ProfScope ps(cls, s0.flops, s0.bytes, st);
+    ConvGroup g; g.n = 1; g.grid[0] = (int)s0.grid; g.p[0] = p;
+    launch_conv_lt<T, WM, WN, SM, SN, true, false>(s0.lt, (unsigned)s0.grid, s0.dyn, st, g);
     SplitFinP f;
     f.slabs = p.slabs; f.slab_stride = p.slab_stride; f.S = p.S; f.bias = p.bias;
     f.dst0 = p.dst0; f.dst1 = p.dst1; f.D0 = p.D0; f.D1 = p.D1; f.Q0 = p.Q0; f.Q1 = p.Q1;
@@ -924,37 +963,80 @@ static int launch_conv_cfg(const nunet_conv_desc* d, hipStream_t st) {
     const int blk = G * (256 / G);
     long long fg = (f.npix + (blk / G) - 1) / (blk / G);
     if (fg > 1024) fg = 1024;
-    if (bnr) NUNET_LAUNCH((splitk_finalize_kernel<T, true>), dim3((unsigned)fg), dim3(blk), 0, st, f);
+    if (s0.bnr) NUNET_LAUNCH((splitk_finalize_kernel<T, true>), dim3((unsigned)fg), dim3(blk), 0, st, f);
     else NUNET_LAUNCH((splitk_finalize_kernel<T, false>), dim3((unsigned)fg), dim3(blk), 0, st, f);
     return nunet_check_launch("conv3x3 (K-split)");
   }
-  if (bnr) launch_conv_lt<T, WM, WN, SM, SN, false, true>(lt, (unsigned)grid, dyn, st, p);
-  else launch_conv_lt<T, WM, WN, SM, SN, false, false>(lt, (unsigned)grid, dyn, st, p);
-  return nunet_check_launch("conv3x3");
+  // one launch for the n problems (the caller grouped only problems of one variant, none of them K-split): sorted by grid size
+  // for the round-robin workgroup map, coefficient tables sized for the largest
+  int order[CONV_GROUP_MAX];
+  for (int k = 0; k < n; ++k) order[k] = k;
+  for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) if (S[order[b]].grid < S[order[a]].grid) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+  ConvGroup g; g.n = n;
+  long total = 0; size_t dyn = 0; double fl = 0, by = 0;
+  for (int k = 0; k < n; ++k) {
+    const ConvSetup& s = S[order[k]];
+    g.grid[k] = (int)s.grid; g.p[k] = s.p; total += s.grid; if (s.dyn > dyn) dyn = s.dyn; fl += s.flops; by += s.bytes;
+  }
+  ProfScope ps(cls, fl, by, st);
+  if (S[0].bnr) launch_conv_lt<T, WM, WN, SM, SN, false, true>(S[0].lt, (unsigned)total, dyn, st, g);
+  else launch_conv_lt<T, WM, WN, SM, SN, false, false>(S[0].lt, (unsigned)total, dyn, st, g);
+  return nunet_check_launch(n > 1 ? "conv3x3 (group)" : "conv3x3");
 }
 
-template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream_t st) {
+// Tile choice (measured per layer on MI355X, tools/conv_layers.py): the standard tiles are 128 pixels x 64 channels
+// (Cout multiple of 64: 2 x 2 waves of 64 x 32) or 256 x 32. They leave a deep level (few pixels) with fewer work
+// items than the chip has CUs; there the 128 x 32 tile (4 workgroups per CU, twice the items) wins by up to 2x and
+// needs no K-split. It also wins for the plain / BN-forward Cout = 32 convs of the first level (one wave per SIMD
+// with the 256-pixel tile). With the BN-backward input transform the small tile loses: every Cout tile repeats the
+// transform of its input tile. Also measured and not kept: the same tiles on 8 waves (32 x 32 per wave: every layer
+// slower, up to 1.35x), one workgroup per CU to leave room for another lane's kernel (-4 % on the step).
+// (round 3, measured and not kept: 576 pixels x 32 channels on 6 waves of 96 x 32 - one balanced round of 256 items at level 0,
+//  the weight stage shared by 4.5 x the pixels, every B fragment feeding three MFMAs - is 10-30 % SLOWER on every level-0 layer:
+//  six waves land 2-2-1-1 on the four SIMDs, the nine staging units per thread push the kernel to 256 registers with spills, and
+//  one workgroup per CU loses what co-resident workgroups still overlap; capping today's kernel at one workgroup per CU costs 20 %.)
+// 0: 128 x 32, 1: 128 x 64, 2: 256 x 32
+static int conv_cfg_of(const nunet_conv_desc* d) {
   const int cout = d->D0 + d->D1;
-  // Tile choice (measured per layer on MI355X, tools/conv_layers.py): the standard tiles are 128 pixels x 64 channels
-  // (Cout multiple of 64: 2 x 2 waves of 64 x 32) or 256 x 32. They leave a deep level (few pixels) with fewer work
-  // items than the chip has CUs; there the 128 x 32 tile (4 workgroups per CU, twice the items) wins by up to 2x and
-  // needs no K-split. It also wins for the plain / BN-forward Cout = 32 convs of the first level (one wave per SIMD
-  // with the 256-pixel tile). With the BN-backward input transform the small tile loses: every Cout tile repeats the
-  // transform of its input tile. Also measured and not kept: the same tiles on 8 waves (32 x 32 per wave: every layer
-  // slower, up to 1.35x), one workgroup per CU to leave room for another lane's kernel (-4 % on the step).
   const long px = (long)d->N * d->H * d->W;
   const long items_std = cout % 64 == 0 ? ceil_div64(px, 128) * (cout / 64) : ceil_div64(px, 256) * (cout / 32);
   const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD);
-  // (round 3, measured and not kept: 576 pixels x 32 channels on 6 waves of 96 x 32 - one balanced round of 256 items at level 0,
-  //  the weight stage shared by 4.5 x the pixels, every B fragment feeding three MFMAs - is 10-30 % SLOWER on every level-0 layer:
-  //  six waves land 2-2-1-1 on the four SIMDs, the nine staging units per thread push the kernel to 256 registers with spills, and
-  //  one workgroup per CU loses what co-resident workgroups still overlap; capping today's kernel at one workgroup per CU costs 20 %.)
-  if (small) return launch_conv_cfg<T, 4, 1, 1, 1>(d, st);                              // 128 pixels x 32 channels
-  if (cout % 64 == 0) return launch_conv_cfg<T, 2, 2, 2, 1>(d, st);
-  return launch_conv_cfg<T, 4, 1, 2, 1>(d, st);
+  if (small) return 0;
+  return cout % 64 == 0 ? 1 : 2;
+}
+template <typename T> static int launch_conv_n(const nunet_conv_desc* const* ds, int n, hipStream_t st) {
+  const int cfg = conv_cfg_of(ds[0]);
+  if (cfg == 0) return launch_conv_cfg<T, 4, 1, 1, 1>(ds, n, st);                            // 128 pixels x 32 channels
+  if (cfg == 1) return launch_conv_cfg<T, 2, 2, 2, 1>(ds, n, st);
+  return launch_conv_cfg<T, 4, 1, 2, 1>(ds, n, st);
+}
+template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream_t st) { return launch_conv_n<T>(&d, 1, st); }
+
+// would this problem be K-split (then it is launched alone: its finalize launch follows it)?
+template <typename T> static int conv_is_split(const nunet_conv_desc* d) {
+  ConvSetup S;
+  const int cfg = conv_cfg_of(d);
+  if (cfg == 0) conv_setup<T, 4, 1, 1, 1>(d, S); else if (cfg == 1) conv_setup<T, 2, 2, 2, 1>(d, S); else conv_setup<T, 4, 1, 2, 1>(d, S);
+  return S.p.S > 1 ? 1 : 0;
 }
 
-extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {
+static int conv_check(const nunet_conv_desc* d);
+// Grouping key of a problem: problems with equal keys (>= 0) may share a launch. -1: launch it alone.
+int nunet_conv_group_key(const nunet_conv_desc* d) {
+  if (!d || conv_check(d) != NUNET_OK) return -1;
+  if (NUNET_DISPATCH(d->dtype, conv_is_split, d)) return -1;
+  return ((d->dtype * 3 + conv_cfg_of(d)) * 2 + (d->bn_y ? 1 : 0)) * 3 + d->in_tf;
+}
+// n problems of one key in one launch (internal: the plan's single-stream schedule)
+int nunet_conv3x3_group(const nunet_conv_desc* const* ds, int n, hipStream_t st) {
+  NUNET_REQUIRE(ds && n >= 1 && n <= CONV_GROUP_MAX, "conv3x3 group: 1..%d problems", CONV_GROUP_MAX);
+  const int key = nunet_conv_group_key(ds[0]);
+  for (int k = 0; k < n; ++k) { const int rc = conv_check(ds[k]); if (rc) return rc; }
+  if (n > 1) for (int k = 0; k < n; ++k) NUNET_REQUIRE(key >= 0 && nunet_conv_group_key(ds[k]) == key, "conv3x3 group: problems of different kernel variants");
+  return NUNET_DISPATCH(ds[0]->dtype, launch_conv_n, ds, n, st);
+}
+
+static int conv_check(const nunet_conv_desc* d) {
   NUNET_REQUIRE(d && d->src0 && d->wpack && d->dst0, "conv3x3: null pointer");
   const int cin = d->C0 + d->C1, cout = d->D0 + d->D1;
   NUNET_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "conv3x3: bad dtype %d", d->dtype);
@@ -992,6 +1074,11 @@ extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {
       NUNET_REQUIRE(d->tf_y && d->tf_fx && d->tf_mean_invstd && d->tf_py % epv == 0, "conv3x3: BN-backward input transform needs y, sums and saved mean/invstd");
     }
   }
+  return NUNET_OK;
+}
+extern "C" int nunet_conv3x3_fwd(const nunet_conv_desc* d, nunet_stream_t s) {
+  const int rc = conv_check(d);
+  if (rc) return rc;
   return NUNET_DISPATCH(d->dtype, launch_conv, d, (hipStream_t)s);
 }
 

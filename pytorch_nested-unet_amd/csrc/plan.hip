@@ -11,6 +11,7 @@
 
 #include <initializer_list>
 #include <functional>
+#include <algorithm>
 
 #include <vector>
 #include <string>
@@ -447,6 +448,7 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   std::vector<hipEvent_t> events[2];   // [0] forward, [1] backward: an event is never re-recorded within one capture
   size_t events_used[2];
   int multistream;
+  int wave;                                // 1: single-stream schedule with grouped launches (Sched::run_wave) instead of lanes
   bool lanes_external;
   std::vector<hipStream_t> cap_streams;   // never-reused streams for capture-time lane continuation
   size_t cap_next;
@@ -686,6 +688,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->seg_lanes[0] = rt->seg_lanes[1] = rt->seg_lanes[2] = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
   { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
+  { const char* e = getenv("NUNET_SCHEDULE"); rt->wave = (e && !strcmp(e, "wave")) ? 1 : 0; }
   for (int l = 0; l < NLANES; ++l) {
     rt->lanes[l] = nullptr;
     if (hipStreamCreateWithFlags(&rt->lanes[l], hipStreamNonBlocking) != hipSuccess) { rt->lanes_ok = false; (void)hipGetLastError(); }
@@ -854,10 +857,20 @@ struct Sched {
   }
 
   // ---- deferred ops: the backward pass collects its ops first (descriptors captured by value), then issues them
-  struct Op { int lane, leaf; float cost; int nrd, nwr; int rd[12], wr[8]; char name[32]; std::function<int(hipStream_t)> fn; };
+  // kind: what the single-stream schedule (run_wave) may group into one launch; the lane schedule runs every op through fn
+  enum { K_GEN = 0, K_CONV = 1 };
+  struct Op { int lane, leaf; float cost; int nrd, nwr; int rd[12], wr[8]; char name[32]; std::function<int(hipStream_t)> fn;
+              int kind; nunet_conv_desc cd; int alg_cin; };
   std::vector<Op> ops;
+  // a 3x3 convolution (forward or input gradient): grouped with other ready convolutions of the same kernel variant by run_wave
+  void add_conv(int lane, std::initializer_list<int> rd, std::initializer_list<int> wr, const nunet_conv_desc& d, int alg_cin = 0) {
+    const double px = (double)d.N * d.H * d.W;
+    add(lane, 0, 6.f + (float)(2.0 * 9 * (d.C0 + d.C1) * (d.D0 + d.D1) * px / 4e8), rd, wr, [d, alg_cin](hipStream_t ls) {
+      g_prof_alg_cin = alg_cin; const int r = nunet_conv3x3_fwd(&d, ls); g_prof_alg_cin = 0; return r; });
+    ops.back().kind = K_CONV; ops.back().cd = d; ops.back().alg_cin = alg_cin;
+  }
   void add(int lane, int leaf, float cost, std::initializer_list<int> rd, std::initializer_list<int> wr, std::function<int(hipStream_t)> fn) {
-    Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0;
+    Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0; o.kind = K_GEN; o.alg_cin = 0;
     for (int x : rd) if (x >= 0) { if (o.nrd < 12) o.rd[o.nrd++] = x; else failed = true; }
     for (int x : wr) if (x >= 0) { if (o.nwr < 8) o.wr[o.nwr++] = x; else failed = true; }
     memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
@@ -865,13 +878,16 @@ struct Sched {
     ops.push_back(std::move(o));
   }
   void add_v(int lane, int leaf, float cost, const int* rd, int nrd, std::function<int(hipStream_t)> fn) {
-    Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0;
+    Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0; o.kind = K_GEN; o.alg_cin = 0;
     for (int q = 0; q < nrd; ++q) if (rd[q] >= 0) { if (o.nrd < 12) o.rd[o.nrd++] = rd[q]; else failed = true; }
     memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
     o.fn = std::move(fn);
     ops.push_back(std::move(o));
   }
   int run_ops();
+  int run_wave();
+  bool wave;                           // single-stream schedule: no lanes, no events; run() picks
+  int run() { return wave ? run_wave() : run_ops(); }
   void end() {
     if (!multi) { stamp(main_s, 0); cur_name[0] = 0; return; }
     hipStream_t st = lane_s[cur_lane];
@@ -955,6 +971,8 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
     if (rt->stamps) { snprintf(cur_name, sizeof(cur_name), "start"); stamp(s, 0); cur_name[0] = 0; }
   }
   multi = rt->multistream != 0 && rt->lanes_ok;
+  wave = rt->wave != 0;
+  if (wave) multi = false;             // one stream: no lanes to fork, no events
   failed = false;
   capturing = false;
   pool = &rt->events[pass]; pool_used = &rt->events_used[pass];
@@ -1018,6 +1036,73 @@ int Sched::run_ops() {
   return rc;
 }
 
+// Single-stream schedule ("wave" mode). ROCm 7.2 replays a hipGraph with parallel branches node by node from the host (3-6 us of
+// host time per node, 2-10 us of extra latency per dependent node around every fork / join, tools/graph_gap_probe*.py) but a
+// single-stream graph as one batch of pre-built packets (0.9 us per node, 0.3 us of host time). And two independent
+// convolutions running side by side cost 1.3-1.4 x one (tools/conv_concurrency_probe.py). So instead of forking lanes the pass is
+// emitted on ONE stream, in dependency order, with the concurrency INSIDE the launches: a list scheduler walks the ops by
+// critical-path priority and puts every ready convolution of the same kernel variant into the launch of the one it picked
+// (nunet_conv3x3_group: up to CONV_GROUP_MAX problems, workgroups dealt round-robin).
+int nunet_conv_group_key(const nunet_conv_desc* d);
+int nunet_conv3x3_group(const nunet_conv_desc* const* ds, int n, hipStream_t st);
+int Sched::run_wave() {
+  const int n = (int)ops.size();
+  std::vector<std::vector<int>> succ(n);
+  std::vector<int> indeg(n, 0), key(n, -1);
+  {
+    std::vector<int> lastw(NRES, -1);
+    std::vector<std::vector<int>> readers(NRES);
+    auto edge = [&](int a, int b) { if (a >= 0 && a != b && std::find(succ[a].begin(), succ[a].end(), b) == succ[a].end()) { succ[a].push_back(b); ++indeg[b]; } };
+    for (int i = 0; i < n; ++i) {
+      const Op& o = ops[i];
+      for (int q = 0; q < o.nrd; ++q) edge(lastw[o.rd[q]], i);
+      for (int q = 0; q < o.nwr; ++q) { edge(lastw[o.wr[q]], i); for (int r : readers[o.wr[q]]) edge(r, i); }
+      for (int q = 0; q < o.nrd; ++q) readers[o.rd[q]].push_back(i);
+      for (int q = 0; q < o.nwr; ++q) { lastw[o.wr[q]] = i; readers[o.wr[q]].clear(); }
+      if (o.kind == K_CONV) key[i] = nunet_conv_group_key(&o.cd);
+    }
+  }
+  std::vector<float> prio(n, 0.f);
+  for (int i = n - 1; i >= 0; --i) { float m = 0.f; for (int s : succ[i]) m = std::max(m, prio[s]); prio[i] = ops[i].cost + m; }
+  std::vector<int> ready;
+  std::vector<char> done(n, 0);
+  for (int i = 0; i < n; ++i) if (indeg[i] == 0) ready.push_back(i);
+  int rc = NUNET_OK, emitted = 0;
+  while (!ready.empty() && rc == NUNET_OK) {
+    int best = 0;
+    for (int q = 1; q < (int)ready.size(); ++q) if (prio[ready[q]] > prio[ready[best]] || (prio[ready[q]] == prio[ready[best]] && ready[q] < ready[best])) best = q;
+    const int p = ready[best];
+    int grp[CONV_GROUP_MAX]; int ng = 0;
+    grp[ng++] = p;
+    if (key[p] >= 0) {
+      // the other ready convolutions of the same variant, most urgent first
+      std::vector<int> cand;
+      for (int q : ready) if (q != p && key[q] == key[p]) cand.push_back(q);
+      std::sort(cand.begin(), cand.end(), [&](int a, int b) { return prio[a] > prio[b] || (prio[a] == prio[b] && a < b); });
+      for (int q : cand) if (ng < CONV_GROUP_MAX) grp[ng++] = q;
+    }
+    if (ng > 1) {
+      const nunet_conv_desc* ds[CONV_GROUP_MAX];
+      for (int k = 0; k < ng; ++k) ds[k] = &ops[grp[k]].cd;
+      rc = nunet_conv3x3_group(ds, ng, main_s);
+      snprintf(cur_name, sizeof(cur_name), "%.12s+%d", ops[p].name, ng - 1);
+    } else {
+      rc = ops[p].fn(main_s);
+      memcpy(cur_name, ops[p].name, sizeof(cur_name));
+    }
+    stamp(main_s, 0); cur_name[0] = 0;
+    for (int k = 0; k < ng; ++k) {
+      const int i = grp[k];
+      done[i] = 1; ++emitted;
+      ready.erase(std::find(ready.begin(), ready.end(), i));
+      for (int s : succ[i]) if (--indeg[s] == 0) ready.push_back(s);
+    }
+  }
+  if (rc == NUNET_OK && emitted != n) { nunet_set_error("plan: single-stream schedule emitted %d of %d ops (dependency cycle)", emitted, n); rc = NUNET_EINVAL; }
+  ops.clear();
+  return rc;
+}
+
 // Lane of a block. Crossing hardware queues costs 5-10 us of dispatch latency per dependency edge, so the assignment
 // decides how many edges of the critical chain (B00>B10>B20>B30>B40>B31>B22>B13>B04 and its mirror in backward) cross
 // lanes: the chain runs on lane 0, the side blocks on lanes 1-3 by anti-diagonal (measured best of seven assignments:
@@ -1060,17 +1145,17 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
   const bool skip_pack = (training_flags & 2) != 0;   // the caller vouches that nunet_plan_update / _repack left the packed weights current
   if (!skip_pack) {
     S.name("pack");
-    hipStream_t ls = S.begin(0, {}, {R_WP + 0, R_WP + 1, R_WP + 2, R_WP + 3, R_WP + 4});
-    if (dt == NUNET_F32) rc = launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, ls);
-    else if (dt == NUNET_BF16) rc = launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
-    else rc = launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
-    S.end();
+    S.add(0, 0, 15.f, {}, {R_WP + 0, R_WP + 1, R_WP + 2, R_WP + 3, R_WP + 4}, [=](hipStream_t ls) {
+      if (dt == NUNET_F32) return launch_pack<float>(params, wpack, P->ptab, P->pack_maxn, ls);
+      if (dt == NUNET_BF16) return launch_pack<bf16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
+      return launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
+    });
   }
   // The x2 upsample of a block output (archs1.py:83,116-131: consumed by exactly one block of the level above) CAN ride in the
   // producer's BatchNorm launch as a second block role (nunet_bn_fwd_desc.up: bit-identical, ten launches fewer per forward).
   // Measured on MI355X, same box, 96x96 bs16 bf16: single-lane step unchanged (2.557 vs 2.554 ms), multi-lane graph step SLOWER
   // (8326 vs 8700 and 8041 vs 8232 img/s): ROCm's graph executor overlaps lanes better with the two short launches than with the
-  // one longer one. Off by default; NUNET_FUSE_UP=1 turns it on (tools/ and the op test exercise the fused form).
+  // one longer one. Off by default; NUNET_FUSE_UP=1 turns it on (the op test exercises the fused form).
   static int fuse_up = -1;
   if (fuse_up < 0) { const char* e = getenv("NUNET_FUSE_UP"); fuse_up = e ? atoi(e) : 0; }
   auto up_consumer = [&](const Node& n) {      // index of the block that upsamples n's output, -1: none
@@ -1085,39 +1170,32 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
     const int rskf = P->sk_floats[i] > 0 ? R_SK + i : -1;
     if (n.up_slot >= 0 && !fuse_up) {
       S.name("B%d%d.upF", n.i, n.j);
-      hipStream_t ls = S.begin(lane, {R_X + (i + 1) * 5 + n.up_slot}, {rb + B_UP});
-      rc = nunet_upsample2x_fwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1],
-                                AB(arena, P->X[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1],
-                                AB(arena, n.up), NBF[i + 1], ls);
-      S.end();
-      if (rc) break;
+      S.add(lane, 0, 7.f, {R_X + (i + 1) * 5 + n.up_slot}, {rb + B_UP}, [=](hipStream_t ls) {
+        return nunet_upsample2x_fwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1],
+                                    AB(arena, P->X[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], AB(arena, n.up), NBF[i + 1], ls);
+      });
     }
     // ---- conv1: raw output y1 + its BatchNorm sums (fixed point) ---------------------------------------------
     {
       const ConvL& L = n.c1;
       nunet_conv_desc d; memset(&d, 0, sizeof(d));
       d.dtype = dt; d.N = c.N; d.H = H; d.W = W;
-      hipStream_t ls;
-      S.name("B%d%d.conv1", n.i, n.j);
-      if (n.in_prefix == 0) {
-        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; ls = S.begin(lane, {R_IMG, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}); }
-        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; ls = S.begin(lane, {rb + B_PIN, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}); }
-      } else {
-        d.src0 = AB(arena, P->X[i]); d.C0 = n.in_prefix * f; d.P0 = P->PX[i];
-        d.src1 = AB(arena, n.up); d.C1 = NBF[i + 1]; d.P1 = NBF[i + 1];
-        ls = S.begin(lane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
-                            n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf});
-      }
       d.wpack = wpack + (size_t)L.wf * es;
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (bn_stat_coeffs)
       d.dst0 = AB(arena, n.y1); d.D0 = f; d.Q0 = f;
       d.stats = training ? (int64_t*)fx_of(arena, P, 0, L.stats) : nullptr;
       if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
-      g_prof_alg_cin = (i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
-      rc = nunet_conv3x3_fwd(&d, ls);
-      g_prof_alg_cin = 0;
-      S.end();
-      if (rc) break;
+      const int alg_cin = (i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
+      S.name("B%d%d.conv1", n.i, n.j);
+      if (n.in_prefix == 0) {
+        if (i == 0) { d.src0 = AB(arena, P->off_img); d.C0 = 32; d.P0 = 32; S.add_conv(lane, {R_IMG, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}, d, alg_cin); }
+        else { d.src0 = AB(arena, n.pin); d.C0 = NBF[i - 1]; d.P0 = NBF[i - 1]; S.add_conv(lane, {rb + B_PIN, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}, d, alg_cin); }
+      } else {
+        d.src0 = AB(arena, P->X[i]); d.C0 = n.in_prefix * f; d.P0 = P->PX[i];
+        d.src1 = AB(arena, n.up); d.C1 = NBF[i + 1]; d.P1 = NBF[i + 1];
+        S.add_conv(lane, {R_X + i * 5 + 0, n.in_prefix > 1 ? R_X + i * 5 + 1 : -1, n.in_prefix > 2 ? R_X + i * 5 + 2 : -1,
+                          n.in_prefix > 3 ? R_X + i * 5 + 3 : -1, rb + B_UP, R_WP + i}, {rb + B_Y1, rb + B_ST1, rskf}, d, alg_cin);
+      }
     }
     // ---- conv2: BatchNorm1 + ReLU applied to y1 on the way into LDS (archs1.py:23-28); the activation a1 is
     // stored on the side for the weight gradient when a backward pass may follow -----------------------------------
@@ -1137,10 +1215,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       d.stats = training ? (int64_t*)fx_of(arena, P, 0, L.stats) : nullptr;
       if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
       S.name("B%d%d.conv2", n.i, n.j);
-      hipStream_t ls = S.begin(lane, {rb + B_Y1, rb + B_ST1, R_WP + i}, {rb + B_Y2, rb + B_ST2, rb + B_A1, rskf});
-      rc = nunet_conv3x3_fwd(&d, ls);
-      S.end();
-      if (rc) break;
+      S.add_conv(lane, {rb + B_Y1, rb + B_ST1, R_WP + i}, {rb + B_Y2, rb + B_ST2, rb + B_A1, rskf}, d);
     }
     // ---- BatchNorm2 + ReLU (+ 2x2 max-pool for the encoder column): the block output has many consumers
     // (convs of the same level, the upsample, the pool, a head) and is materialised once in its level-buffer slot ------
@@ -1165,21 +1240,21 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
         if (q >= 0) { b.up = AB(arena, P->exec[q].up); b.PU = f; rup = R_BLK + q * B_STRIDE + B_UP; }
       }
       S.name("B%d%d.bnF2", n.i, n.j);
-      hipStream_t ls = S.begin(lane, {rb + B_Y2, rb + B_ST2}, {R_X + i * 5 + n.out_slot, rpin, rup});
-      rc = nunet_bn_relu_fwd(&b, ls);
-      S.end();
+      S.add(lane, 0, 6.f, {rb + B_Y2, rb + B_ST2}, {R_X + i * 5 + n.out_slot, rpin, rup}, [=](hipStream_t ls) { return nunet_bn_relu_fwd(&b, ls); });
     }
   }
   if (rc == NUNET_OK) {
     const long long plane = (long long)c.N * c.num_classes * c.H * c.W;
     for (size_t k = 0; k < P->heads.size() && rc == NUNET_OK; ++k) {
+      const Head hd = P->heads[k];
       S.name("head%d.F", (int)k);
-      hipStream_t ls = S.begin(0, {R_X + P->heads[k].slot}, {R_LOGITS});
-      rc = nunet_head_fwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)P->heads[k].slot * NBF[0] * es), P->PX[0],
-                          params + P->heads[k].w_off, params + P->heads[k].b_off, logits + plane * k, ls);
-      S.end();
+      S.add(0, 0, 10.f, {R_X + hd.slot}, {R_LOGITS + 0}, [=](hipStream_t ls) {
+        return nunet_head_fwd(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)hd.slot * NBF[0] * es), P->PX[0],
+                              params + hd.w_off, params + hd.b_off, logits + plane * k, ls);
+      });
     }
   }
+  if (rc == NUNET_OK) rc = S.run();
   S.join();  // always rejoin the caller's stream (also on error: a capture must not be left forked)
   if (rc == NUNET_OK && S.failed) { nunet_set_error("plan_forward: lane scheduler overflow (capture stream pool / dependency lists)"); rc = NUNET_EINVAL; }
   return rc;
@@ -1539,7 +1614,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     nunet_bnr_desc bd; memset(&bd, 0, sizeof(bd));
     if (kt >= 0) bd = bnr_of(kt);
     S.name("head%d.B", (int)k);
-    S.add(0, 0, 0.f, {R_X + h.slot, R_DLOGITS, kt >= 0 ? R_BLK + kt * B_STRIDE + B_Y2 : -1}, {R_GX + h.slot, R_GSV + 30 + (int)k, kt >= 0 ? R_GSV + 2 * kt + 1 : -1}, [=](hipStream_t ls) {
+    S.add(0, 0, 15.f, {R_X + h.slot, R_DLOGITS, kt >= 0 ? R_BLK + kt * B_STRIDE + B_Y2 : -1}, {R_GX + h.slot, R_GSV + 30 + (int)k, kt >= 0 ? R_GSV + 2 * kt + 1 : -1}, [=](hipStream_t ls) {
       return nunet_head_bwd_bnr(dt, c.N, c.H, c.W, NBF[0], c.num_classes, AB(arena, P->X[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
                                 params + h.w_off, dlogits + plane * k, AB(arena, P->GX[0] + (size_t)h.slot * NBF[0] * es), P->PX[0],
                                 acc, gsr + h.gs, HEAD_SLABS, kt >= 0 ? &bd : nullptr, ls);
@@ -1585,7 +1660,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       const bool fused = lk == LW_HEAD;   // taken by the head backward, which completed the gradient
       if (!fused) {
         S.name("B%d%d.bnR2", n.i, n.j);
-        S.add(lane, 0, 0.f, {r_gxo, rb + B_Y2}, {r_v2}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_reduce(&b2, ls); });
+        S.add(lane, 0, 9.f, {r_gxo, rb + B_Y2}, {r_v2}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_reduce(&b2, ls); });
       }
     }
 
@@ -1605,7 +1680,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       d.bn_gamma = params + L1.g_off; d.bn_beta = params + L1.be_off; d.bn_sums = (int64_t*)fx_of(arena, P, 1, L1.bsum);
       if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
       S.name("B%d%d.dgrad2", n.i, n.j);
-      S.add(lane, 0, 0.f, {r_gxo, rb + B_Y2, rb + B_Y1, R_WP + i}, {r_dy2, r_da1, r_v2, r_v1, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
+      S.add_conv(lane, {r_gxo, rb + B_Y2, rb + B_Y1, R_WP + i}, {r_dy2, r_da1, r_v2, r_v1, rsk}, d);
     }
     // ---- dgrad of conv1 with BatchNorm1's apply pass on the way in; the first block has no input gradient and
     // runs the stand-alone apply pass for its weight gradient instead
@@ -1622,11 +1697,11 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       S.name("B%d%d.dgrad1", n.i, n.j);
       if (n.in_prefix == 0) {
         d.dst0 = AB(arena, P->off_gpin[k]); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1];
-        S.add(lane, 0, 0.f, {r_da1, rb + B_Y1, r_v1, R_WP + i}, {r_dy1, rl + L_GPIN, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
+        S.add_conv(lane, {r_da1, rb + B_Y1, r_v1, R_WP + i}, {r_dy1, rl + L_GPIN, rsk}, d);
         // through MaxPool2d(2,2) into x_{i-1,0}
         const int acc = written[i - 1][0] ? 1 : 0;
         S.name("B%d%d.poolB", n.i, n.j);
-        S.add(lane, 0, 0.f, {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0}, [=](hipStream_t ls) {
+        S.add(lane, 0, 8.f, {rl + L_GPIN, R_X + (i - 1) * 5 + 0}, {R_GX + (i - 1) * 5 + 0}, [=](hipStream_t ls) {
           return nunet_maxpool2x2_bwd(dt, c.N, P->hl[i - 1], P->wl[i - 1], NBF[i - 1], AB(arena, P->X[i - 1]), P->PX[i - 1],
                                       AB(arena, P->off_gpin[k]), NBF[i - 1], AB(arena, P->GX[i - 1]), P->PX[i - 1], acc, ls);
         });
@@ -1635,13 +1710,13 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
         d.dst0 = AB(arena, P->GX[i]); d.D0 = n.in_prefix * f; d.Q0 = P->PX[i]; d.acc_slot_w = f;
         for (int q = 0; q < n.in_prefix; ++q) { if (written[i][q]) d.acc0_mask |= 1u << q; written[i][q] = true; }
         d.dst1 = AB(arena, P->off_gup[k]); d.D1 = NBF[i + 1]; d.Q1 = NBF[i + 1];
-        S.add(lane, 0, 0.f, {r_da1, rb + B_Y1, r_v1, R_WP + i},
-              {r_dy1, R_GX + i * 5 + 0, n.in_prefix > 1 ? R_GX + i * 5 + 1 : -1, n.in_prefix > 2 ? R_GX + i * 5 + 2 : -1,
-               n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP, rsk}, [=](hipStream_t ls) { return nunet_conv3x3_fwd(&d, ls); });
+        S.add_conv(lane, {r_da1, rb + B_Y1, r_v1, R_WP + i},
+                   {r_dy1, R_GX + i * 5 + 0, n.in_prefix > 1 ? R_GX + i * 5 + 1 : -1, n.in_prefix > 2 ? R_GX + i * 5 + 2 : -1,
+                    n.in_prefix > 3 ? R_GX + i * 5 + 3 : -1, rl + L_GUP, rsk}, d);
         // through the bilinear upsample into x_{i+1,up_slot}
         const int acc = written[i + 1][n.up_slot] ? 1 : 0;
         S.name("B%d%d.upB", n.i, n.j);
-        S.add(lane, 0, 0.f, {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot}, [=](hipStream_t ls) {
+        S.add(lane, 0, 11.f, {rl + L_GUP}, {R_GX + (i + 1) * 5 + n.up_slot}, [=](hipStream_t ls) {
           return nunet_upsample2x_bwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1], AB(arena, P->off_gup[k]), NBF[i + 1],
                                       AB(arena, P->GX[i + 1] + (size_t)n.up_slot * NBF[i + 1] * es), P->PX[i + 1], acc, ls);
         });
@@ -1656,7 +1731,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       b1.dbias = gv1; b1.dgamma = gv1 + L1.cout; b1.dbeta = gv1 + 2 * L1.cout;
       b1.dy = dy1; b1.PDY = f;
       S.name("B%d%d.bnA1", n.i, n.j);
-      S.add(lane, 0, 0.f, {r_da1, rb + B_Y1, r_v1}, {r_dy1}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_apply(&b1, ls); });
+      S.add(lane, 0, 9.f, {r_da1, rb + B_Y1, r_v1}, {r_dy1}, [=](hipStream_t ls) { return nunet_bn_relu_bwd_apply(&b1, ls); });
     }
     // ---- both weight gradients of the block in one launch (leaves of the dependency graph: only the slab reduce
     // reads them); conv1's problem first: it may carry the first layer's algorithmic Cin for the profiler
@@ -1684,8 +1759,9 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       // back until the chain reaches the deep levels (B31 ..., grid-starved kernels that leave most CUs idle): they run
       // on lane 4 behind a dependency on the gradient that B22's upsample-backward hands to B31
       int wl = wlane, r_gate = -1;     // (measured +1.9 % on the step)
-      if (!P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
-      S.add(wl, 1, 0.f, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up, r_gate}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
+      if (!P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3 && !S.wave) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
+      const float wcost = 8.f + (float)(2.0 * 9 * ((double)L1.cinpad + L2.cinpad) * f * (double)c.N * H * W / 3.5e8);
+      S.add(wl, 1, wcost, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up, r_gate}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
             [=](hipStream_t ls) {
               g_prof_alg_cin = alg_cin; int r = nunet_conv3x3_wgrad_pair(&w1, &w2, ls); g_prof_alg_cin = 0;
               // the block's K-split slabs are summed right behind it on the same lane: 15 small launches hidden beside the
@@ -1716,7 +1792,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       }
     }
   }
-  if (rc == NUNET_OK) rc = S.run_ops();
+  if (rc == NUNET_OK) rc = S.run();
   if (leave_open && rc == NUNET_OK && !S.failed) {
     // the producers of the first bucket: last-writer events of every gradient resource of the phase-1 nodes and the heads
     // (single-lane issue: none - everything is in order on the caller's stream, which the caller makes its side stream wait for)

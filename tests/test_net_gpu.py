@@ -737,3 +737,38 @@ def test_segmented_step_program_equals_the_single_graph(synth):
         del ts, m
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_single_stream_schedule_with_grouped_convs_equals_the_lane_schedule(dtype, synth):
+    """NUNET_SCHEDULE=wave: the pass emitted on ONE stream in dependency order by a critical-path list scheduler, every ready 3x3
+    convolution of the same kernel variant riding in the launch of the one it picked (nunet_conv3x3_group: up to 4 problems per
+    launch, workgroups dealt round-robin). A grouped problem computes exactly what its own launch computes, so the step is
+    bit-identical to the multi-lane schedule's - parameters, momentum, BatchNorm buffers, losses - with deep supervision on."""
+    import os
+    from nunet_amd.trainer import TrainStep
+    n, hw = 16, 96
+    torch.manual_seed(13)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, True).state_dict().items()}
+    batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=400 + k) for k in range(3)]
+    outs = []
+    for sched in ("lanes", "wave"):
+        os.environ["NUNET_SCHEDULE"] = sched
+        try:
+            m = nunet_amd.archs.NestedUNet(1, 3, True, dtype=dtype)
+            m.load_state_dict(sd)
+            m = m.to(DEV).train()
+            ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2)          # the plan reads the schedule when it is created
+        finally:
+            os.environ.pop("NUNET_SCHEDULE", None)
+        ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+        if sched == "wave":
+            info = ts.g_fb.info()
+            assert info["lanes"] == 1, info                        # one stream: ROCm's batch-submit path, no parallel branches
+        for img, msk in batches:
+            ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (ts.eng.flat_params, ts.mom, ts.eng.bnbuf, ts.loss_out)])
+        del ts, m
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
