@@ -248,7 +248,7 @@ def main():
     if not args.no_roofline and rank == 0 and world == 1:     # single-process leg: no collectives inside
         # Live per-kernel timing of the same step: eager, single-lane issue (kernels alone on the device), every launch
         # through hipExtLaunchKernelGGL with a start/stop event pair = the dispatch's own begin/end timestamps (the
-        # figures rocprofv3 --kernel-trace reports; profiles/r02_summary.md holds that trace of the same command).
+        # figures rocprofv3 --kernel-trace reports; profiles/r03_summary.md holds that trace of the same command).
         L.check(L.lib().nunet_plan_set_multistream(ts.pl.handle, 0), "set_multistream")
         for _ in range(2):
             ts._fwd_bwd(); ts._opt()
@@ -282,14 +282,14 @@ def main():
         # FETCH_SIZE x2 correction of MI355X_MICROARCH.md): attached only when the file was collected on THESE kernel
         # sources and this workload; otherwise null (a stale figure is worse than none)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
             same = pmc.get("kernel_source_sha16") == kernel_source_hash() and pmc.get("workload") == [args.dtype, n, hw]
             rec = pmc.get("classes", {}).get(top["name"])
             if same and rec:
                 roofline["traffic"] = rec["hbm_bytes_per_launch_corrected"]
-                roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roofline["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             else:
-                roofline["traffic_note"] = "profiles/r02_pmc_traffic.json was collected on different kernel sources / workload: not attached"
+                roofline["traffic_note"] = "profiles/r03_pmc_traffic.json was collected on different kernel sources / workload: not attached"
         except Exception:
             pass
         roofline["kernel"] = top["name"]

@@ -1,14 +1,16 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- tools/make_profiles.sh): every rocprofv3 pass behind profiles/rNN_*.
-# Outputs under gpurun_out/prof_final/; tools/summarize_profiles.py turns them into the tracked files.
+# Run on the GPU box (gpurun -- bash tools/make_profiles.sh [SIZE BATCH OUTDIR]): every rocprofv3 pass behind profiles/rNN_*.
+# Outputs under gpurun_out/OUTDIR (default prof_final, workload 96 16); tools/summarize_profiles.py turns them into the tracked files.
 # Each rocprofv3 invocation profiles `python3 bench.py` directly (no wrapper between -- and the program); counter
 # passes carry only --kernel-trace beside --pmc.
 set -e
+SIZE=${1:-96}; BATCH=${2:-16}; OUT=${3:-prof_final}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_final
+O=$R/gpurun_out/$OUT
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline"
+W="--size $SIZE --batch $BATCH --no-cpu-baseline --no-roofline --no-fp32"
+B="$R/bench.py --steps 20 --warmup 5 $W"
 keep() {  # keep() <dir> <pattern> <dest>: copy the one csv we need, drop the rest
   F=$(find $1 -name "$2" | head -1); cp "$F" "$3"; rm -rf $1
 }
@@ -19,7 +21,7 @@ NUNET_MULTISTREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s
 keep $O/single "*kernel_stats.csv" $O/single_kernel_stats.csv
 echo "single-lane done"
 # counter passes: eager (no hipGraph), single lane, 8 steps
-P="$R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-graph"
+P="$R/bench.py --steps 6 --warmup 2 --no-graph $W"
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" \

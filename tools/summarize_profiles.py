@@ -3,8 +3,10 @@
 kernel class (what bench.py attaches as roofline.traffic), MFMA / LDS / instruction-mix counters per kernel."""
 import collections, csv, hashlib, json, os, re, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(R, "gpurun_out", "prof_final")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SIZE = int(sys.argv[2]) if len(sys.argv) > 2 else 96
+BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+src = os.path.join(R, "gpurun_out", sys.argv[4] if len(sys.argv) > 4 else "prof_final")
 P = os.path.join(R, "profiles")
 STEPS = 27          # 20 timed + 5 warm-up + 2 capture warm-up passes
 PMC_STEPS = 8 + 0   # eager: 6 timed + 2 warm-up (no capture warm-up with --no-graph)
@@ -63,7 +65,7 @@ def main():
     shutil.copy(os.path.join(src, "single_kernel_stats.csv"), os.path.join(P, tag + "_bench_kernel_stats_single_lane.csv"))
     lines = {}
     for n in ("multi", "single"):
-        line = open(os.path.join(src, n + ".json")).read().strip().splitlines()[-1]
+        line = [ln for ln in open(os.path.join(src, n + ".json")).read().strip().splitlines() if ln.startswith("{")][-1]
         lines[n] = json.loads(line)
         open(os.path.join(P, tag + ("_bench_under_rocprof.json" if n == "multi" else "_bench_under_rocprof_single_lane.json")), "w").write(line + "\n")
     # ---- HBM traffic per kernel and per bench class: (2 x FETCH_SIZE + WRITE_SIZE) KB, per launch
@@ -79,7 +81,7 @@ def main():
         if c: classes[c][0] += n; classes[c][1] += b * n
     d = os.path.join(R, "pytorch_nested-unet_amd", "csrc")
     out = {"kernel_source_sha16": sha16([os.path.join(d, x) for x in ("conv3x3.hip", "elementwise.hip", "plan.hip", "common.h")]),
-           "workload": ["bf16", 16, 96],
+           "workload": ["bf16", BATCH, SIZE],
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager single-lane bench); "
                      "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: gfx950 FETCH_SIZE counts half of wide coalesced reads (MI355X_MICROARCH.md)",
            "classes": {c: {"launches": v[0], "hbm_bytes_per_launch_corrected": v[1] / v[0]} for c, v in classes.items()},
