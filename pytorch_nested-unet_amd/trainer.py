@@ -96,6 +96,8 @@ class TrainStep:
         mode = os.environ.get("NUNET_DP_MODE", "auto")
         self.dp_auto = mode == "auto" and self.dp
         self.dp_mode = 1 if mode == "auto" else int(mode)
+        if self.dp and self.dp_mode == 3 and dist.get_backend(process_group) == "gloo":
+            self.dp_mode = 1             # a gloo exchange is a host round trip: it cannot sit inside the step's graph
         self.dp_choice = None        # {layout: ms per step} when the layout was chosen by measurement
         self.use_graph = use_graph
         # optimiser step layout: 0 = unpack, SGD, (next forward's) pack as three streaming launches; 2 (default) = unpack
@@ -377,7 +379,12 @@ class TrainStep:
         for mode in modes:
             self.dp_mode = mode
             if mode == 3:
-                self._capture_in_graph_exchange(s)
+                try:
+                    self._capture_in_graph_exchange(s)
+                except Exception as e:           # a runtime that cannot capture the collectives: layout 1 stays (every rank runs the same code)
+                    print("[nunet] data-parallel layout 3 (exchange inside the step's graph) could not be captured: %s" % e)
+                    times.append(float("inf"))
+                    continue
                 run = self.g_fb.replay
             else:
                 self._capture_one_pass(s)
