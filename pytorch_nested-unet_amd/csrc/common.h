@@ -226,6 +226,19 @@ __device__ __forceinline__ void bn_stat_coeffs(const BnStatArgs& a, int c, float
   invstd = 1.0f / sqrtf(var + a.eps);
 }
 
+// running_mean / running_var update of nn.BatchNorm2d in training mode (momentum form, unbiased variance): ONE operation order for
+// every kernel that performs it (contraction off: whether `a * b + c * d` fuses is otherwise decided per call site, and the
+// BatchNorm taken in a conv's loader must leave the same bits as the stand-alone kernel)
+__device__ __forceinline__ void bn_running_update(float* rm, float* rv, int c, float momentum, float mean_full, float var, float M) {
+#pragma clang fp contract(off)
+  const float unb = M > 1.f ? var * (M / (M - 1.f)) : var;
+  const float keep = 1.f - momentum;
+  const float a = keep * rm[c], b = momentum * mean_full;
+  rm[c] = a + b;
+  const float cc = keep * rv[c], d = momentum * unb;
+  rv[c] = cc + d;
+}
+
 template <typename T> struct Vec16 {
   // zero-initialised: set() of a 16-bit element read-modify-writes its 32-bit word, and doing that on an
   // indeterminate word is undefined (it miscompiled for fp16 on the odd elements of words 0 and 1)

@@ -669,11 +669,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvGroup grp)
       s_coef[c] = sc; s_coef[p.Cin + c] = __builtin_fmaf(-mean, sc, p.tf_beta[c]);
       if (vbid == 0 && p.tf_training) {
         if (p.tf_save) { p.tf_save[c] = mean; p.tf_save[p.Cin + c] = invstd; }
-        if (p.tf_rm) {
-          const float unb = p.M > 1.f ? var * (p.M / (p.M - 1.f)) : var;
-          p.tf_rm[c] = (1.f - p.tf_momentum) * p.tf_rm[c] + p.tf_momentum * mf;
-          p.tf_rv[c] = (1.f - p.tf_momentum) * p.tf_rv[c] + p.tf_momentum * unb;
-        }
+        if (p.tf_rm) bn_running_update(p.tf_rm, p.tf_rv, c, p.tf_momentum, mf, var, p.M);
       }
     }
     if (vbid == 0 && p.tf_training && tid == 0 && p.tf_nbt) *p.tf_nbt += 1;

@@ -218,11 +218,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(BnFwdP p) {
     if (blockIdx.x == 0 && p.training) {
       p.save[c] = mean;
       p.save[p.C + c] = invstd;
-      if (p.rm) {
-        const float unb = M > 1.f ? var * (M / (M - 1.f)) : var;
-        p.rm[c] = (1.f - p.momentum) * p.rm[c] + p.momentum * mf;
-        p.rv[c] = (1.f - p.momentum) * p.rv[c] + p.momentum * unb;
-      }
+      if (p.rm) bn_running_update(p.rm, p.rv, c, p.momentum, mf, var, M);
     }
   }
   if (blockIdx.x == 0 && p.training && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
