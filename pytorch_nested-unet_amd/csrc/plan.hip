@@ -1011,7 +1011,10 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
       if (cs2 != hipStreamCaptureStatusActive) { const bool keep = g_dry_run; g_dry_run = false; seg_pick_lanes(rt, main_s); g_dry_run = keep; }
       else for (int q = 0; q < 3; ++q) rt->seg_lanes[q] = rt->lanes[q + 1];
     }
-    for (int q = 0; q < 3; ++q) lane_s[q + 1] = rt->seg_lanes[q];
+    // NUNET_SEG_LANES = 2: every side block on ONE side stream; 3: two; 4 (default): three
+    static int nl = -1;
+    if (nl < 0) { const char* e = getenv("NUNET_SEG_LANES"); nl = e ? atoi(e) : 4; if (nl < 2) nl = 2; if (nl > 4) nl = 4; }
+    for (int q = 0; q < 3; ++q) lane_s[q + 1] = rt->seg_lanes[q % (nl - 1)];
     lane_s[4] = lane_s[3];
   }
   if (multi) {
