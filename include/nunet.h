@@ -126,6 +126,9 @@ typedef struct {
   int32_t max_slabs;                /* capacity of the caller's slab buffer (0: unlimited, i.e. nunet_conv3x3_wgrad_slabs of it) */
   int32_t target_wgs;               /* workgroups the launch should reach through the K-split (0: 256) */
   int64_t dw_floats;                /* capacity of `dw` in floats: the launch is refused (NUNET_EINVAL) unless every slab it would write fits */
+  int32_t item_shape;               /* output channels x input channels one work item covers: 0 / 11 = 32 x 32 (default), 21 = 64 x 32
+                                     * (needs Cout % 64 == 0, else 32 x 32), 12 = 32 x 64 (needs Cin >= 64). Wider items read the two operand
+                                     * tiles fewer times but keep fewer workgroups resident; nunet_conv3x3_wgrad_slabs depends on it. */
 } nunet_wgrad_desc;
 
 /* Partial weight gradients: the contraction over pixels is split into nunet_conv3x3_wgrad_slabs(d) slices; slice s
@@ -386,6 +389,12 @@ int nunet_plan_repack(nunet_plan* p, const float* params, void* arena, size_t ar
  * before anything the caller enqueues on `s` afterwards, and a capture of `s` records the
  * lanes as parallel branches of the same hipGraph. */
 int nunet_plan_set_multistream(nunet_plan* p, int32_t enable);
+/* How the plan issues its ops. NUNET_SCHEDULE_LANES (default): forked streams, captured as parallel branches of one hipGraph.
+ * NUNET_SCHEDULE_WAVE: ONE stream, dependency order from a critical-path list scheduler, every ready 3x3 convolution of the same
+ * kernel variant grouped into one launch - a single-stream graph (ROCm replays those as one batch of pre-built packets) whose
+ * concurrency lives inside the launches. Bit-identical results; set before the first forward / capture. */
+enum { NUNET_SCHEDULE_LANES = 0, NUNET_SCHEDULE_WAVE = 1 };
+int nunet_plan_set_schedule(nunet_plan* p, int32_t schedule);
 /* debug/test access to an intermediate: name like "x0_0", "x2_1" (block
  * outputs, NHWC). Returns byte offset into arena; fills pitch/channels. */
 int64_t nunet_plan_feature(const nunet_plan* p, int32_t i, int32_t j, int32_t* pitch,

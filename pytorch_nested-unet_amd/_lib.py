@@ -68,7 +68,7 @@ class WgradDesc(C.Structure):
                 ("src0", _vp), ("C0", _i32), ("P0", _i32),
                 ("src1", _vp), ("C1", _i32), ("P1", _i32),
                 ("dy", _vp), ("Cout", _i32), ("PY", _i32),
-                ("dw", _vp), ("slab_stride", _i64), ("max_slabs", _i32), ("target_wgs", _i32), ("dw_floats", _i64)]
+                ("dw", _vp), ("slab_stride", _i64), ("max_slabs", _i32), ("target_wgs", _i32), ("dw_floats", _i64), ("item_shape", _i32)]
 
 
 class BnFwdDesc(C.Structure):
@@ -157,6 +157,7 @@ _SIG = {
     "nunet_plan_sgd": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
     "nunet_plan_feature": (_i64, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "nunet_plan_set_multistream": (_i32, [_vp, _i32]),
+    "nunet_plan_set_schedule": (_i32, [_vp, _i32]),
     "nunet_plan_set_lanes": (_i32, [_vp, C.POINTER(_vp), _i32]),
     "nunet_profile_begin": (_i32, []),
     "nunet_profile_end": (_i32, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),

@@ -1415,13 +1415,13 @@ __global__ __launch_bounds__(192) void wgrad_pair_kernel(WgP pa, WgP pb, int na)
 // 10-15 % on the levels with enough pixel tiles to keep the K-split wide; 64 input channels per item (1 x 2, for the
 // Cout = 32 level) need 260 registers - one workgroup per CU - and lose 40 %: kept as an instantiation for diagnostics only.
 struct WgTile { int A, B; };
-static WgTile wgrad_tile(int cout, int cin, long long px) {
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("NUNET_WGRAD_TILE"); force = e ? atoi(e) : 0; }   // diagnostics: 11 | 12 | 21: force a shape; 2: 2 x 1 only for Cin >= 128
-  // (inside the multi-lane step the 2 x 1 items LOSE what they win alone - 8160 vs 8330 img/s at 96x96 bs16: at two workgroups per
-  //  CU they leave the chain's kernels less room - so the default stays 32 x 32 items everywhere)
-  if (force == 12) return cin >= 64 ? WgTile{1, 2} : WgTile{1, 1};
-  if (cout % 64 == 0 && (force == 21 || (force == 1 && px >= 4096) || (force == 2 && px >= 4096 && cin >= 128))) return WgTile{2, 1};
+// (inside the multi-lane step the 2 x 1 items LOSE what they win alone - 8160 vs 8330 img/s at 96x96 bs16: at two workgroups per
+//  CU they leave the chain's kernels less room - so the plan asks for 32 x 32 items everywhere; the wider shapes are descriptor
+//  options - nunet_wgrad_desc.item_shape - covered by the op tests and tools/wgrad_layers.py)
+static WgTile wgrad_tile(const nunet_wgrad_desc* d) {
+  const int cout = d->Cout, cin = d->C0 + d->C1;
+  if (d->item_shape == 21 && cout % 64 == 0) return WgTile{2, 1};
+  if (d->item_shape == 12 && cin >= 64) return WgTile{1, 2};
   return WgTile{1, 1};
 }
 template <typename T> static size_t wgrad_lds_bytes(WgTile t) {
@@ -1431,7 +1431,7 @@ template <typename T> static size_t wgrad_lds_bytes(WgTile t) {
 // K-split slices of a weight-gradient problem: enough work items for `target` workgroups, at most one
 // slice per 128-pixel tile and at most `max_slabs` (the caller's slab capacity). Pure function of the descriptor.
 static int wgrad_slices(const nunet_wgrad_desc* d, const TileGeom& g) {
-  const WgTile wt = wgrad_tile(d->Cout, d->C0 + d->C1, (long long)d->N * d->H * d->W);
+  const WgTile wt = wgrad_tile(d);
   const int otiles = ceil_div(d->Cout, 32 * wt.A) * ceil_div(d->C0 + d->C1, 32 * wt.B);
   const int nMT = g.tilesX * g.tilesY * g.tilesG;
   int ks = ceil_div(d->target_wgs > 0 ? d->target_wgs : 256, otiles);
@@ -1455,7 +1455,7 @@ template <typename T> static long wgrad_setup(const nunet_wgrad_desc* d, WgP& p)
   p.NI = g.NI; p.TH = g.TH; p.TW = g.TW; p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.tilesG = g.tilesG; p.SH = g.SH;
   p.SHinv = g.SH ? (unsigned)(((1ull << 32) + g.SH - 1) / g.SH) : 0u;
   p.invTX = fastdiv_inv(g.tilesX); p.invTY = fastdiv_inv(g.tilesY);
-  const WgTile wt = wgrad_tile(p.Cout, p.Cin, (long long)p.N * p.H * p.W);
+  const WgTile wt = wgrad_tile(d);
   p.nCoT = ceil_div(p.Cout, 32 * wt.A);
   p.nCiT = ceil_div(p.Cin, 32 * wt.B);
   p.nMT = g.tilesX * g.tilesY * g.tilesG;
@@ -1492,7 +1492,7 @@ template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStre
   const long grid = wgrad_setup<T>(d, p);
   double fl, by; wgrad_prof<T>(d, p, fl, by);
   ProfScope ps(p.Cout == 32 ? PC_WGRAD_1x4 : PC_WGRAD_2x2, fl, by, st);
-  const WgTile wt = wgrad_tile(p.Cout, p.Cin, (long long)p.N * p.H * p.W);
+  const WgTile wt = wgrad_tile(d);
   const int key = wt.A * 10 + wt.B;
   if (p.SH) {
     if (key == 21) launch_wgrad_one<T, true, 2, 1>(grid, p, st);
@@ -1512,7 +1512,7 @@ template <typename T> static int launch_wgrad_pair(const WgPairArgs* w, hipStrea
   const long ga = wgrad_setup<T>(w->a, pa), gb = wgrad_setup<T>(w->b, pb);
   double fa, ba, fb, bb; wgrad_prof<T>(w->a, pa, fa, ba);
   { const int keep = g_prof_alg_cin; g_prof_alg_cin = 0; wgrad_prof<T>(w->b, pb, fb, bb); g_prof_alg_cin = keep; }
-  const WgTile ta = wgrad_tile(pa.Cout, pa.Cin, (long long)pa.N * pa.H * pa.W), tb = wgrad_tile(pb.Cout, pb.Cin, (long long)pb.N * pb.H * pb.W);
+  const WgTile ta = wgrad_tile(w->a), tb = wgrad_tile(w->b);
   const int key = (ta.A * 10 + ta.B) * 100 + tb.A * 10 + tb.B;
   // the item-shape pairs a VGGBlock produces (conv1 | conv2): 1x1 | 1x1, 2x1 | 2x1, and the mixed forms of the diagnostic rules;
   // anything else (different tiling modes, other shape pairs): two launches
@@ -1557,6 +1557,7 @@ static int wgrad_check(const nunet_wgrad_desc* d) {
   }
   NUNET_REQUIRE(d->slab_stride == 0 || d->slab_stride >= 9LL * d->Cout * (d->C0 + d->C1), "wgrad: slab_stride smaller than one slab");
   NUNET_REQUIRE(d->max_slabs >= 0 && d->target_wgs >= 0, "wgrad: max_slabs / target_wgs");
+  NUNET_REQUIRE(d->item_shape == 0 || d->item_shape == 11 || d->item_shape == 12 || d->item_shape == 21, "wgrad: item_shape %d (0 | 11 | 12 | 21)", d->item_shape);
   {
     // every slab the launch will write must fit what the caller says `dw` holds
     const long long stride = d->slab_stride > 0 ? d->slab_stride : 9LL * d->Cout * (d->C0 + d->C1);

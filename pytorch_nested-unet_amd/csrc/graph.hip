@@ -218,14 +218,7 @@ namespace {
 struct SegInstr { int op; hipStream_t st; hipEvent_t ev; hipGraphExec_t exec; };   // op 0 launch, 1 record, 2 wait
 struct SegRec {
   bool dry = false;
-  bool lazy = false;                         // NUNET_SEG_LAZY=1: merge event records - a lane is cut only when another lane asks for one of
-                                             // its events (33 instead of 55 segments per step, but consumers then wait for the lane's
-                                             // whole tail: 2.64 vs 2.33 ms; off)
   hipStream_t main = nullptr;
-  // lazy records: events recorded on a stream since its last cut (the latest stands for all of them: same-stream order),
-  // and, once flushed, the event that was really recorded in their place
-  std::vector<std::pair<hipEvent_t, hipStream_t>> pending;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> alias;
   std::vector<hipEvent_t> needed;            // sorted after the dry pass
   std::vector<hipStream_t> capturing;        // streams with an open segment
   std::vector<SegInstr> prog;
@@ -252,20 +245,6 @@ struct SegRec {
     graphs.push_back(g); execs.push_back(x);
     prog.push_back(SegInstr{0, st, nullptr, x});
   }
-  hipEvent_t resolve(hipEvent_t ev) {         // the event to wait for in place of `ev`; flushes its stream if `ev` is still pending
-    for (auto& a : alias) if (a.first == ev) return a.second;
-    hipStream_t ps = nullptr;
-    for (auto& p : pending) if (p.first == ev) ps = p.second;
-    if (!ps) return ev;
-    hipEvent_t latest = nullptr;
-    for (auto& p : pending) if (p.second == ps) latest = p.first;          // recorded in issue order: the last one is the stream's tail
-    cut(ps);
-    prog.push_back(SegInstr{1, ps, latest, nullptr});
-    for (size_t k = 0; k < pending.size();) {
-      if (pending[k].second == ps) { alias.push_back({pending[k].first, latest}); pending.erase(pending.begin() + k); } else ++k;
-    }
-    return latest;
-  }
   void touch(hipStream_t st) {
     if (dry || is_cap(st)) return;
     const hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
@@ -291,7 +270,7 @@ bool seg_wait(hipStream_t st, hipEvent_t ev) {
   SegRec* r = g_seg;
   if (!r) return false;
   if (r->dry) { r->needed.push_back(ev); return true; }
-  hipEvent_t e = r->lazy ? r->resolve(ev) : ev;
+  hipEvent_t e = ev;
   // one wait per (stream, event) between two cuts of the stream is enough
   for (size_t k = r->prog.size(); k-- > 0;) {
     const SegInstr& i = r->prog[k];
@@ -307,7 +286,8 @@ bool seg_record(hipEvent_t ev, hipStream_t st) {
   SegRec* r = g_seg;
   if (!r) return false;
   if (r->dry || !r->is_needed(ev)) return true;
-  if (r->lazy) { r->pending.push_back({ev, st}); return true; }      // recorded when (if) somebody asks: see resolve()
+  // (merging the records lazily - a lane cut only when another lane asks for one of its events - gives 33 instead of 55 segments
+  //  per step but 2.64 instead of 2.33 ms: consumers then wait for the producer lane's whole tail; measured, not kept)
   r->cut(st);
   r->prog.push_back(SegInstr{1, st, ev, nullptr});
   return true;
@@ -319,7 +299,6 @@ extern "C" int nunet_seg_begin(nunet_stream_t s, int32_t dry) {
   NUNET_REQUIRE(!g_seg && !g_cap.active, "seg_begin: a recording / capture is already active on this thread");
   SegRec* r = new SegRec();
   r->dry = dry != 0; r->main = (hipStream_t)s;
-  { const char* e = getenv("NUNET_SEG_LAZY"); r->lazy = e && atoi(e) == 1; }
   if (!r->dry) { r->needed = g_seg_needed; std::sort(r->needed.begin(), r->needed.end()); }
   g_seg = r;
   g_dry_run = r->dry;

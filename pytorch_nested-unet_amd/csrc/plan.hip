@@ -688,7 +688,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->seg_lanes[0] = rt->seg_lanes[1] = rt->seg_lanes[2] = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
   { const char* e = getenv("NUNET_MULTISTREAM"); rt->multistream = e ? atoi(e) : 1; }
-  { const char* e = getenv("NUNET_SCHEDULE"); rt->wave = (e && !strcmp(e, "wave")) ? 1 : 0; }
+  rt->wave = 0;
   for (int l = 0; l < NLANES; ++l) {
     rt->lanes[l] = nullptr;
     if (hipStreamCreateWithFlags(&rt->lanes[l], hipStreamNonBlocking) != hipSuccess) { rt->lanes_ok = false; (void)hipGetLastError(); }
@@ -1011,10 +1011,7 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
       if (cs2 != hipStreamCaptureStatusActive) { const bool keep = g_dry_run; g_dry_run = false; seg_pick_lanes(rt, main_s); g_dry_run = keep; }
       else for (int q = 0; q < 3; ++q) rt->seg_lanes[q] = rt->lanes[q + 1];
     }
-    // NUNET_SEG_LANES = 2: every side block on ONE side stream; 3: two; 4 (default): three
-    static int nl = -1;
-    if (nl < 0) { const char* e = getenv("NUNET_SEG_LANES"); nl = e ? atoi(e) : 4; if (nl < 2) nl = 2; if (nl > 4) nl = 4; }
-    for (int q = 0; q < 3; ++q) lane_s[q + 1] = rt->seg_lanes[q % (nl - 1)];
+    for (int q = 0; q < 3; ++q) lane_s[q + 1] = rt->seg_lanes[q];
     lane_s[4] = lane_s[3];
   }
   if (multi) {
@@ -1154,24 +1151,15 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       return launch_pack<f16_t>(params, wpack, P->ptab, P->pack_maxn, ls);
     });
   }
-  // The x2 upsample of a block output (archs1.py:83,116-131: consumed by exactly one block of the level above) CAN ride in the
-  // producer's BatchNorm launch as a second block role (nunet_bn_fwd_desc.up: bit-identical, ten launches fewer per forward).
-  // Measured on MI355X, same box, 96x96 bs16 bf16: single-lane step unchanged (2.557 vs 2.554 ms), multi-lane graph step SLOWER
-  // (8326 vs 8700 and 8041 vs 8232 img/s): ROCm's graph executor overlaps lanes better with the two short launches than with the
-  // one longer one. Off by default; NUNET_FUSE_UP=1 turns it on (the op test exercises the fused form).
-  static int fuse_up = -1;
-  if (fuse_up < 0) { const char* e = getenv("NUNET_FUSE_UP"); fuse_up = e ? atoi(e) : 0; }
-  auto up_consumer = [&](const Node& n) {      // index of the block that upsamples n's output, -1: none
-    for (size_t q = 0; q < P->exec.size(); ++q)
-      if (P->exec[q].up_slot >= 0 && P->exec[q].i + 1 == n.i && P->exec[q].up_slot == n.out_slot) return (int)q;
-    return -1;
-  };
+  // (The x2 upsample of a block output can ride in the producer's BatchNorm launch as a second block role - nunet_bn_fwd_desc.up,
+  // bit-identical, ten launches fewer per forward. Measured on MI355X, same box: single-lane step unchanged (2.557 vs 2.554 ms),
+  // multi-lane graph step SLOWER (8326 vs 8700 and 8041 vs 8232 img/s). The plan keeps the stand-alone launch.)
   for (size_t k = 0; k < P->exec.size() && rc == NUNET_OK; ++k) {
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
     const int lane = lane_of(P, n), rb = R_BLK + (int)k * B_STRIDE;
     const int rskf = P->sk_floats[i] > 0 ? R_SK + i : -1;
-    if (n.up_slot >= 0 && !fuse_up) {
+    if (n.up_slot >= 0) {
       S.name("B%d%d.upF", n.i, n.j);
       S.add(lane, 0, 7.f, {R_X + (i + 1) * 5 + n.up_slot}, {rb + B_UP}, [=](hipStream_t ls) {
         return nunet_upsample2x_fwd(dt, c.N, P->hl[i + 1], P->wl[i + 1], NBF[i + 1],
@@ -1237,13 +1225,8 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
         const int q = blk_index(P, i + 1, 1);
         if (q >= 0) { b.pooled = AB(arena, P->exec[q].pin); b.PP = f; rpin = R_BLK + q * B_STRIDE + B_PIN; }
       }
-      int rup = -1;
-      if (fuse_up) {
-        const int q = up_consumer(n);
-        if (q >= 0) { b.up = AB(arena, P->exec[q].up); b.PU = f; rup = R_BLK + q * B_STRIDE + B_UP; }
-      }
       S.name("B%d%d.bnF2", n.i, n.j);
-      S.add(lane, 0, 6.f, {rb + B_Y2, rb + B_ST2}, {R_X + i * 5 + n.out_slot, rpin, rup}, [=](hipStream_t ls) { return nunet_bn_relu_fwd(&b, ls); });
+      S.add(lane, 0, 6.f, {rb + B_Y2, rb + B_ST2}, {R_X + i * 5 + n.out_slot, rpin}, [=](hipStream_t ls) { return nunet_bn_relu_fwd(&b, ls); });
     }
   }
   if (rc == NUNET_OK) {
@@ -1885,6 +1868,12 @@ extern "C" int nunet_plan_set_lanes(nunet_plan* P, nunet_stream_t* lanes, int32_
   for (int l = 0; l < NLANES; ++l) rt->lanes[l] = (hipStream_t)lanes[l % n];   // caller-owned streams
   rt->lanes_ok = true;
   rt->lanes_external = true;
+  return NUNET_OK;
+}
+
+extern "C" int nunet_plan_set_schedule(nunet_plan* P, int32_t schedule) {
+  NUNET_REQUIRE(P && (schedule == NUNET_SCHEDULE_LANES || schedule == NUNET_SCHEDULE_WAVE), "plan_set_schedule: bad args");
+  rt_of(P)->wave = schedule == NUNET_SCHEDULE_WAVE ? 1 : 0;
   return NUNET_OK;
 }
 

@@ -29,14 +29,19 @@ from .parallel import allreduce_flat_, broadcast_flat_
 
 class TrainStep:
     def __init__(self, model, batch_shape, lr=1e-3, momentum=0.9, weight_decay=1e-4, nesterov=False,
-                 use_graph=True, process_group=None, keep_grads=True, fused_update=None, loss="BCEDiceLoss", input_u8=False):
+                 use_graph=True, process_group=None, keep_grads=True, fused_update=None, loss="BCEDiceLoss", input_u8=False,
+                 schedule=None, segmented=None):
         """loss: 'BCEDiceLoss' (reference losses.py:103-117, the default of trains.py:58) or 'LovaszHingeLoss'
         (losses.py:120-129, the loss of the reference's published table README.md:102-108; one class only) - both run
         inside the step's graph and under data parallel.
         input_u8: the step's inputs are the DECODED uint8 batch (images [N,H,W,C], masks [N,H,W,K] in {0,255}) plus optional
         per-sample augmentation codes; Normalize, /255, the mask scaling, rot90 / flips and the layout change of the
         reference's sample pipeline (dataset.py:66-74, trains.py:258-266) run as the first two launches of the step's graph
-        (step_u8). Only uint8 crosses PCIe and the per-step NCHW->NHWC launch of the float path is gone."""
+        (step_u8). Only uint8 crosses PCIe and the per-step NCHW->NHWC launch of the float path is gone.
+        schedule: 'lanes' (default: the plan's forked streams, one multi-branch hipGraph) or 'wave' (one stream, list scheduler,
+        grouped convolution launches); segmented: record the lane schedule as a program of single-stream graph segments instead of
+        one graph. Both alternatives are bit-identical to the default and slower on ROCm 7.2; None reads
+        NUNET_SCHEDULE / NUNET_SEGMENTED (tools)."""
         self.model = model
         self.eng = model.engine()
         dev = self.eng.device
@@ -45,6 +50,11 @@ class TrainStep:
         self.ncls = model.num_classes
         x0 = torch.zeros(batch_shape, dtype=torch.float32, device=dev)
         self.pl = model.plan_for(x0)
+        self.schedule = schedule or os.environ.get("NUNET_SCHEDULE", "lanes")
+        if self.schedule not in ("lanes", "wave"):
+            raise L.NunetError("TrainStep: schedule %r is not 'lanes' or 'wave'" % (self.schedule,))
+        L.check(L.lib().nunet_plan_set_schedule(self.pl.handle, 1 if self.schedule == "wave" else 0), "plan_set_schedule")
+        self.segmented = (os.environ.get("NUNET_SEGMENTED", "0") == "1") if segmented is None else bool(segmented)
         self.heads = self.pl.heads
         self.x = x0
         self.t = torch.zeros((n, self.ncls, h, w), dtype=torch.float32, device=dev)
@@ -323,12 +333,12 @@ class TrainStep:
         if self.dp and self.dp_mode == 3 and dist.get_backend(self.pg) == "gloo":
             self.dp_mode = 1                                # a host-side exchange cannot be a graph node
         if not self.dp:
-            # the whole step, recorded once on a side stream and replayed on the caller's: as ONE multi-branch hipGraph (default), or
-            # - NUNET_SEGMENTED=1 - as a program of single-stream graph segments over the plan's lanes with the cross-lane
+            # the whole step, recorded once on a side stream and replayed on the caller's: as ONE hipGraph (default), or
+            # - segmented=True - as a program of single-stream graph segments over the plan's lanes with the cross-lane
             # dependencies as events between graph launches (csrc/graph.hip nunet_seg_*: explicit node -> queue placement on lanes
-            # chosen by measurement; 2.56 vs 1.91 ms per step on MI355X: every segment launch costs ~10 us on its lane)
+            # chosen by measurement; 2.33 vs 1.91 ms per step on MI355X: every segment launch costs 10-13 us on its lane)
             body = lambda: (self._fwd_bwd(), self._opt())
-            self.g_fb = _SegProgram(s, body) if os.environ.get("NUNET_SEGMENTED", "0") == "1" else _NativeGraph(s, body)
+            self.g_fb = _SegProgram(s, body) if self.segmented else _NativeGraph(s, body)
         else:
             if self.dp_auto:
                 self._choose_layout(s)

@@ -704,7 +704,7 @@ def test_step_from_decoded_uint8_batches(dtype, synth):
 
 
 def test_segmented_step_program_equals_the_single_graph(synth):
-    """The step recorded as a program of single-stream graph segments over the plan's lanes (NUNET_SEGMENTED=1: nunet_seg_*, cross-lane
+    """The step recorded as a program of single-stream graph segments over the plan's lanes (TrainStep(segmented=True): nunet_seg_*, cross-lane
     dependencies as event records / waits between graph launches on streams chosen by measurement) computes exactly what the
     one multi-branch hipGraph computes: bit-identical parameters, momentum and BatchNorm buffers after three steps. (A dropped
     dependency would show as a race here: the program keeps only the event records some other lane waits on.)"""
@@ -715,18 +715,14 @@ def test_segmented_step_program_equals_the_single_graph(synth):
     sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, True).state_dict().items()}
     batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=300 + k) for k in range(3)]
     outs = []
-    for seg in ("0", "1"):
-        os.environ["NUNET_SEGMENTED"] = seg
-        try:
-            m = nunet_amd.archs.NestedUNet(1, 3, True, dtype="bf16")
-            m.load_state_dict(sd)
-            m = m.to(DEV).train()
-            ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2)
-            ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
-        finally:
-            os.environ.pop("NUNET_SEGMENTED", None)
-        assert isinstance(ts.g_fb, _SegProgram) == (seg == "1")
-        if seg == "1":
+    for seg in (False, True):
+        m = nunet_amd.archs.NestedUNet(1, 3, True, dtype="bf16")
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, segmented=seg)
+        ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+        assert isinstance(ts.g_fb, _SegProgram) == seg
+        if seg:
             info = ts.g_fb.info()
             print("segmented program:", info)
             assert info["graph_launches"] > 4 and info["event_waits"] >= info["event_records"] > 0 and info["kernel_nodes"] > 100
@@ -741,7 +737,7 @@ def test_segmented_step_program_equals_the_single_graph(synth):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_single_stream_schedule_with_grouped_convs_equals_the_lane_schedule(dtype, synth):
-    """NUNET_SCHEDULE=wave: the pass emitted on ONE stream in dependency order by a critical-path list scheduler, every ready 3x3
+    """TrainStep(schedule='wave') / nunet_plan_set_schedule: the pass emitted on ONE stream in dependency order by a critical-path list scheduler, every ready 3x3
     convolution of the same kernel variant riding in the launch of the one it picked (nunet_conv3x3_group: up to 4 problems per
     launch, workgroups dealt round-robin). A grouped problem computes exactly what its own launch computes, so the step is
     bit-identical to the multi-lane schedule's - parameters, momentum, BatchNorm buffers, losses - with deep supervision on."""
@@ -753,14 +749,10 @@ def test_single_stream_schedule_with_grouped_convs_equals_the_lane_schedule(dtyp
     batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=400 + k) for k in range(3)]
     outs = []
     for sched in ("lanes", "wave"):
-        os.environ["NUNET_SCHEDULE"] = sched
-        try:
-            m = nunet_amd.archs.NestedUNet(1, 3, True, dtype=dtype)
-            m.load_state_dict(sd)
-            m = m.to(DEV).train()
-            ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2)          # the plan reads the schedule when it is created
-        finally:
-            os.environ.pop("NUNET_SCHEDULE", None)
+        m = nunet_amd.archs.NestedUNet(1, 3, True, dtype=dtype)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, schedule=sched)
         ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
         if sched == "wave":
             info = ts.g_fb.info()

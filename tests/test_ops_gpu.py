@@ -158,23 +158,54 @@ def test_conv3x3_wgrad(dt, shape):
 
 
 
-def wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, slabs, max_slabs=0, target=0):
+def wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, slabs, max_slabs=0, target=0, item_shape=0):
     return L.WgradDesc(dt, n, h, w, L.ptr(s0), c0, p0, L.ptr(s1), c1, c1, L.ptr(dyb), cout, cout, L.ptr(slabs),
-                       9 * cout * (c0 + c1), max_slabs, target, 0 if slabs is None else slabs.numel())
+                       9 * cout * (c0 + c1), max_slabs, target, 0 if slabs is None else slabs.numel(), item_shape)
 
 
-def wgrad_run(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, target=0):
+def wgrad_run(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, target=0, item_shape=0):
     """K-split slabs (plain stores, every slab fully overwritten: pre-filled with garbage) + the fixed-order reduce."""
     cin = c0 + c1
-    probe = wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, None, 0, target)
+    probe = wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, None, 0, target, item_shape)
     ks = L.lib().nunet_conv3x3_wgrad_slabs(C.byref(probe))
     assert ks >= 1
     slabs = torch.full((ks * 9 * cout * cin,), 1e30, dtype=torch.float32, device=DEV)
-    d = wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, slabs, ks, target)
+    d = wgrad_desc(dt, n, h, w, s0, c0, p0, s1, c1, dyb, cout, slabs, ks, target, item_shape)
     L.check(L.lib().nunet_conv3x3_wgrad(C.byref(d), L.stream()), "wgrad")
     dw = torch.full((9 * cout * cin,), 3.0, dtype=torch.float32, device=DEV)
     L.check(L.lib().nunet_wgrad_reduce(L.ptr(slabs), 9 * cout * cin, ks, 9 * cout * cin, L.ptr(dw), 0, L.stream()), "wgrad_reduce")
     return dw
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
+@pytest.mark.parametrize("item_shape,shape", [
+    (21, (2, 20, 24, 64, 32, 64)),      # 64 Cout x 32 Cin items, two sources, ragged pixel tiles
+    (21, (16, 12, 12, 64, 0, 128)),     # stacked-rows tiling
+    (21, (2, 8, 8, 32, 0, 32)),         # Cout not a multiple of 64: falls back to 32 x 32
+    (12, (2, 20, 24, 64, 32, 32)),      # 32 x 64 items; Cin = 96: the second input tile is half empty
+    (12, (3, 12, 20, 128, 0, 32)),
+    (12, (7, 3, 5, 32, 0, 32)),         # fewer than 64 input channels: falls back
+])
+def test_conv3x3_wgrad_item_shapes(dt, item_shape, shape):
+    """nunet_wgrad_desc.item_shape: wider work items (A x B planes of [pixels][32 channels] in LDS, one fragment feeding A or B MFMAs)
+    compute the same gradient as the default 32 x 32 items - against torch and, per element, within fp32 summation-order noise of
+    the default shape (the K-split differs, the arithmetic does not)."""
+    n, h, w, c0, c1, cout = shape
+    g = torch.Generator().manual_seed(31)
+    cin = c0 + c1
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    s0 = nhwc(x[:, :c0], dt, pitch=c0 + 64)
+    s1 = nhwc(x[:, c0:], dt) if c1 else None
+    dyb = nhwc(dy, dt)
+    dw = wgrad_run(dt, n, h, w, s0, c0, c0 + 64, s1, c1, dyb, cout, item_shape=item_shape)
+    dw0 = wgrad_run(dt, n, h, w, s0, c0, c0 + 64, s1, c1, dyb, cout)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(q(x, dt).double(), wt, padding=1).backward(q(dy, dt).double())
+    gout = torch.zeros(cout * cin * 9, dtype=torch.float32, device=DEV)
+    L.check(L.lib().nunet_unpack_wgrad(L.ptr(dw), cout, cin, cin, L.ptr(gout), 0, L.stream()), "unpack")
+    assert rel_err(gout.view(cout, cin, 3, 3).cpu(), wt.grad) < (5e-5 if dt == L.F32 else 1e-3), (DT[dt], shape)
+    assert rel_err(dw.cpu(), dw0.cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])

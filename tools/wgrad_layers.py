@@ -34,7 +34,7 @@ def time_graph(fn):
 
 def desc(H, c0, c1, cout, target):
     s0 = t(N, H, H, c0); s1 = t(N, H, H, c1) if c1 else None; dy = t(N, H, H, cout)
-    d = L.WgradDesc(dt, N, H, H, L.ptr(s0), c0, c0, L.ptr(s1), c1, c1, L.ptr(dy), cout, cout, None, 9 * cout * (c0 + c1), 0, target, 0)
+    d = L.WgradDesc(dt, N, H, H, L.ptr(s0), c0, c0, L.ptr(s1), c1, c1, L.ptr(dy), cout, cout, None, 9 * cout * (c0 + c1), 0, target, 0, int(os.environ.get("ITEM_SHAPE", "0")))
     ks = L.lib().nunet_conv3x3_wgrad_slabs(C.byref(d))
     slabs = torch.empty(ks * 9 * cout * (c0 + c1), dtype=torch.float32, device="cuda"); keep.append(slabs)
     d.dw = L.ptr(slabs).value; d.max_slabs = ks; d.dw_floats = slabs.numel()
