@@ -109,6 +109,9 @@ typedef struct {
   float tf_momentum, tf_eps;
   float* tf_dgamma; float* tf_dbeta; float* tf_dbias;
   void* tf_store; int32_t tf_ps;
+  int32_t tile;                     /* workgroup tile, pixels x output channels: 0 = chosen from the shape (the measured policy), 1 = 128 x 32,
+                                     * 2 = 128 x 64, 3 = 256 x 32, 4 = 256 x 64 (2 and 4 need Cout % 64 == 0). Results do not depend on it
+                                     * except through the K-split (fp32 summation order) of grid-starved layers. */
 } nunet_conv_desc;
 
 /* y = conv(cat(src0,src1)) + bias. Also used as dgrad with the flipped,
@@ -441,8 +444,15 @@ void nunet_graph_destroy(nunet_graph* graph);
 /* streams; dry = 0 records. nunet_seg_end returns the program (NULL after a   */
 /* dry pass). The stream must outlive the program: it replays on it.           */
 /* ------------------------------------------------------------------------ */
+/* mode NUNET_SEG_FLAGS: every lane stream captures ONE single-stream graph for  */
+/* the whole step and the cross-lane dependencies become device-side flags      */
+/* (a one-thread signal kernel on the producer lane, a one-thread polling kernel */
+/* on the consumer lane; csrc/graph.hip). Needs the lanes on distinct hardware   */
+/* queues (the plan picks them by measurement); a wait that is not satisfied     */
+/* within 4 s sets an error word and the NEXT nunet_seg_launch fails.            */
+enum { NUNET_SEG_RECORD = 0, NUNET_SEG_DRY = 1, NUNET_SEG_FLAGS = 2 };
 typedef struct nunet_seg nunet_seg;
-int nunet_seg_begin(nunet_stream_t stream, int32_t dry);
+int nunet_seg_begin(nunet_stream_t stream, int32_t mode);
 int nunet_seg_end(nunet_stream_t stream, nunet_seg** out);
 /* replay, ordered after what the caller queued on `stream`; `stream` continues after the program's last segment */
 int nunet_seg_launch(nunet_seg* prog, nunet_stream_t stream);

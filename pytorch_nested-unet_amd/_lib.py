@@ -60,7 +60,7 @@ class ConvDesc(C.Structure):
                 ("tf_gamma", _vp), ("tf_beta", _vp), ("tf_conv_bias", _vp),
                 ("tf_running_mean", _vp), ("tf_running_var", _vp), ("tf_nbt", _vp), ("tf_mean_invstd", _vp),
                 ("tf_momentum", _f32), ("tf_eps", _f32),
-                ("tf_dgamma", _vp), ("tf_dbeta", _vp), ("tf_dbias", _vp), ("tf_store", _vp), ("tf_ps", _i32)]
+                ("tf_dgamma", _vp), ("tf_dbeta", _vp), ("tf_dbias", _vp), ("tf_store", _vp), ("tf_ps", _i32), ("tile", _i32)]
 
 
 class WgradDesc(C.Structure):

@@ -160,7 +160,9 @@ template <typename T, int WM_, int WN_, int SM_, int SN_> struct ConvCfg {
   static constexpr int KC = 64 / (int)sizeof(T);  // channels per LDS chunk (64 B per pixel)
   static constexpr int KS = KC / 16;              // MFMA k-steps per tap per chunk
   static constexpr int PS = KC + EPV;             // padded pixel stride (80 B)
-  static constexpr int HPMAX = BM + BM / 2;       // halo pixel capacity
+  // halo pixel capacity. The 256 x 64 tile keeps it at 344 (a 16 x 16 tile has 324 halo pixels, 8 x 32 has 340): with 384 its
+  // arena (halo + 46 KB of weights) is 2 KB past half of the CU's LDS and only one workgroup would be resident
+  static constexpr int HPMAX = (SM * SN == 4) ? 344 : BM + BM / 2;
   static constexpr int UH = (HPMAX * 4 + NT - 1) / NT;
   static constexpr int UW = (9 * BN * 4 + NT - 1) / NT;
   static constexpr int OS = BN + EPV;             // epilogue staging row stride (elements)
@@ -209,6 +211,21 @@ static inline int conv_coef_floats(int lt, int cin, bool bnr, int cout) { return
 // tools/conv_concurrency_probe.py). Workgroups are dealt to the problems round-robin (problem k owns `grid[k]` of them, sorted
 // ascending), so all problems start together instead of one after the other.
 struct ConvGroup { int n; int grid[CONV_GROUP_MAX]; ConvP p[CONV_GROUP_MAX]; };
+
+// XCD-aware placement (for speed only, any placement is correct): workgroups are dealt round-robin over the 8 XCDs, each with its
+// own 4 MB L2, so blocks b and b + 8 share an L2 and b, b + 1 never do. Work items that read the same data are CONSECUTIVE in item
+// order (the Cout tiles of one pixel tile of a conv; the Cout x Cin tiles of one pixel slice of a weight gradient; neighbouring
+// pixel tiles, whose halos overlap): taking item = block would send them to eight different L2s, each of which fetches the tile
+// from memory again. The map below hands every XCD one contiguous range of the items instead: block b (XCD b % 8, the (b / 8)-th
+// block that XCD receives) takes item base(b % 8) + b / 8.
+#ifndef NUNET_XCD_REMAP
+#define NUNET_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_remap(int b, int G) {
+  if (!NUNET_XCD_REMAP) return b;
+  const int x = b & 7, l = b >> 3, q = G >> 3, rem = G & 7;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + l;
+}
 __device__ __forceinline__ void conv_group_decode(const ConvGroup& g, int b, int& k, int& v) {
   int base = 0, prevg = 0, live = g.n;
   k = 0; v = b;
@@ -637,7 +654,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvGroup grp)
       }
     }
   };
-  int item = vbid;
+  // (a group's problems interleave their workgroups, so block -> XCD is no longer vbid % 8: no remap there)
+  int item = grp.n == 1 ? xcd_remap(vbid, vgrid) : vbid;
   if (item >= p.nItems) return;
   Item cur = decode(item);
   set_hgp(cur);
@@ -1005,6 +1023,7 @@ static int launch_conv_cfg(const nunet_conv_desc* const* ds, int n, hipStream_t 
 // 0: 128 x 32, 1: 128 x 64, 2: 256 x 32
 static int conv_cfg_of(const nunet_conv_desc* d) {
   const int cout = d->D0 + d->D1;
+  if (d->tile >= 1 && d->tile <= 4) return d->tile - 1;
   const long px = (long)d->N * d->H * d->W;
   const long items_std = cout % 64 == 0 ? ceil_div64(px, 128) * (cout / 64) : ceil_div64(px, 256) * (cout / 32);
   const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD);
@@ -1015,6 +1034,7 @@ template <typename T> static int launch_conv_n(const nunet_conv_desc* const* ds,
   const int cfg = conv_cfg_of(ds[0]);
   if (cfg == 0) return launch_conv_cfg<T, 4, 1, 1, 1>(ds, n, st);                            // 128 pixels x 32 channels
   if (cfg == 1) return launch_conv_cfg<T, 2, 2, 2, 1>(ds, n, st);
+  if (cfg == 3) return launch_conv_cfg<T, 4, 1, 2, 2>(ds, n, st);                            // 256 x 64: 64 x 64 per wave, every fragment feeds two MFMAs
   return launch_conv_cfg<T, 4, 1, 2, 1>(ds, n, st);
 }
 template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream_t st) { return launch_conv_n<T>(&d, 1, st); }
@@ -1023,7 +1043,7 @@ template <typename T> static int launch_conv(const nunet_conv_desc* d, hipStream
 template <typename T> static int conv_is_split(const nunet_conv_desc* d) {
   ConvSetup S;
   const int cfg = conv_cfg_of(d);
-  if (cfg == 0) conv_setup<T, 4, 1, 1, 1>(d, S); else if (cfg == 1) conv_setup<T, 2, 2, 2, 1>(d, S); else conv_setup<T, 4, 1, 2, 1>(d, S);
+  if (cfg == 0) conv_setup<T, 4, 1, 1, 1>(d, S); else if (cfg == 1) conv_setup<T, 2, 2, 2, 1>(d, S); else if (cfg == 3) conv_setup<T, 4, 1, 2, 2>(d, S); else conv_setup<T, 4, 1, 2, 1>(d, S);
   return S.p.S > 1 ? 1 : 0;
 }
 
@@ -1032,7 +1052,7 @@ static int conv_check(const nunet_conv_desc* d);
 int nunet_conv_group_key(const nunet_conv_desc* d) {
   if (!d || conv_check(d) != NUNET_OK) return -1;
   if (NUNET_DISPATCH(d->dtype, conv_is_split, d)) return -1;
-  return ((d->dtype * 3 + conv_cfg_of(d)) * 2 + (d->bn_y ? 1 : 0)) * 3 + d->in_tf;
+  return ((d->dtype * 4 + conv_cfg_of(d)) * 2 + (d->bn_y ? 1 : 0)) * 3 + d->in_tf;
 }
 // n problems of one key in one launch (internal: the plan's single-stream schedule)
 int nunet_conv3x3_group(const nunet_conv_desc* const* ds, int n, hipStream_t st) {
@@ -1070,6 +1090,7 @@ static int conv_check(const nunet_conv_desc* d) {
                   "conv3x3: fused BN-backward reduce needs one dense, assign-only destination");
   }
   NUNET_REQUIRE(d->in_tf >= 0 && d->in_tf <= 2, "conv3x3: in_tf %d", d->in_tf);
+  NUNET_REQUIRE(d->tile >= 0 && d->tile <= 4 && ((d->tile != 2 && d->tile != 4) || cout % 64 == 0), "conv3x3: tile %d with Cout=%d", d->tile, cout);
   if (d->in_tf) {
     NUNET_REQUIRE(d->C1 == 0 && cin <= 1024, "conv3x3: an input transform needs a single source (C1 == 0) of at most 1024 channels");
     NUNET_REQUIRE(d->tf_gamma && d->tf_beta, "conv3x3: input transform needs gamma and beta");
@@ -1397,15 +1418,19 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, int bid) {
 }
 
 template <typename T, bool ST, int A, int B>
-__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) { wgrad_body<T, ST, A, B>(p, blockIdx.x); }
+__global__ __launch_bounds__(192) void wgrad_kernel(WgP p) { wgrad_body<T, ST, A, B>(p, xcd_remap((int)blockIdx.x, (int)gridDim.x)); }
 
 // Two independent weight-gradient problems in ONE launch (the two convolutions of a VGGBlock finish
 // their dY at the same point of the backward pass): one kernel boundary less per block and twice
 // the workgroups to fill the chip.
 template <typename T, bool ST, int A1, int B1, int A2, int B2>
-__global__ __launch_bounds__(192) void wgrad_pair_kernel(WgP pa, WgP pb, int na) {
-  if ((int)blockIdx.x < na) wgrad_body<T, ST, A1, B1>(pa, blockIdx.x);
-  else wgrad_body<T, ST, A2, B2>(pb, blockIdx.x - na);
+__global__ __launch_bounds__(192) void wgrad_pair_kernel(WgP pa, WgP pb, int na, int na_pad) {
+  // (problem a's share of the grid is padded to a multiple of 8 - at most 7 idle blocks - so that block -> XCD is (local block) % 8
+  //  in both problems and each gets its own xcd_remap)
+  if ((int)blockIdx.x < na_pad) {
+    const int v = xcd_remap((int)blockIdx.x, na_pad);
+    if (v < na) wgrad_body<T, ST, A1, B1>(pa, v);
+  } else wgrad_body<T, ST, A2, B2>(pb, xcd_remap((int)blockIdx.x - na_pad, (int)gridDim.x - na_pad));
 }
 
 // Item shape of a problem, a pure function of its extents. The kernel is bound by the latency of its staging loads,
@@ -1484,7 +1509,8 @@ template <typename T, bool ST, int A1, int B1, int A2, int B2> static void launc
   const size_t lds = l1 > l2 ? l1 : l2;
   static bool once = false;
   if (!once) { wgrad_allow_lds(wgrad_pair_kernel<T, ST, A1, B1, A2, B2>, lds); once = true; }
-  NUNET_LAUNCH((wgrad_pair_kernel<T, ST, A1, B1, A2, B2>), dim3((unsigned)(ga + gb)), dim3(192), lds, st, pa, pb, (int)ga);
+  const long ga_pad = (ga + 7) / 8 * 8;
+  NUNET_LAUNCH((wgrad_pair_kernel<T, ST, A1, B1, A2, B2>), dim3((unsigned)(ga_pad + gb)), dim3(192), lds, st, pa, pb, (int)ga, (int)ga_pad);
 }
 
 template <typename T> static int launch_wgrad(const nunet_wgrad_desc* d, hipStream_t st) {

@@ -214,10 +214,94 @@ extern "C" void nunet_graph_destroy(nunet_graph* G) {
 // ---------------------------------------------------------------------------------------------------------
 thread_local bool g_dry_run = false;
 
+// ---------------------------------------------------------------------------------------------------------
+// Flag-synchronised lanes (recording mode 2). Every lane stream captures ONE single-stream graph for the whole step - the form
+// ROCm replays as a batch of pre-built packets - and the cross-lane dependencies become device-side flags instead of graph edges
+// or events between graph launches:
+//   record of an event some other lane waits for  ->  flags[f] = step       (one thread, release, agent scope)
+//   wait for an event recorded on another lane    ->  poll flags[f] >= step (one thread per flag, s_sleep between polls)
+// All the records and waits a lane collects between two of its kernels ride in ONE lane_sync_kernel (the command processor's
+// ~2 us per dispatch is shared by all queues: every node counts). `step` is the lane's own replay counter, bumped by the lane's
+// first sync kernel, so flags never need a reset and a value left by the previous replay cannot satisfy a wait. Data visibility rides on the ordinary kernel boundaries: the signal
+// kernel starts after its lane's producer kernel has completed (release at the end of a kernel), the consumer kernel starts after
+// the wait kernel has exited (acquire at the start of a kernel); only the flag itself is accessed with agent-scope atomics.
+// The lanes must sit on different hardware queues (a wait kernel ahead of the signal it waits for in the SAME queue would never
+// end): the plan picks them by measured overlap (seg_pick_lanes) and the recording is refused when fewer than the lanes it
+// uses are distinct. A wait that is not satisfied within LANE_WAIT_TIMEOUT_S sets the program's error word (host-pinned) and
+// exits, so a broken schedule fails loudly at the next launch instead of hanging the GPU.
+// ---------------------------------------------------------------------------------------------------------
+constexpr unsigned long long LANE_WAIT_TIMEOUT_TICKS = 400000000ull;   // s_memrealtime runs at 100 MHz: 4 s
+constexpr int LANE_SYNC_MAX = 12;          // signals / waits per sync kernel (more: a second kernel)
+struct LaneSyncP { unsigned* flags; unsigned* ctr; unsigned* err; int bump, nsig, nwait; unsigned short sig[LANE_SYNC_MAX], wait[LANE_SYNC_MAX]; };
+__global__ __launch_bounds__(64) void lane_sync_kernel(LaneSyncP p) {
+  __shared__ unsigned s_step;
+  const int t = threadIdx.x;
+  if (t == 0) { unsigned v = *p.ctr; if (p.bump) { ++v; *p.ctr = v; } s_step = v; }
+  __syncthreads();
+  const unsigned step = s_step;
+  if (t < p.nsig) __hip_atomic_store(p.flags + p.sig[t], step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (t >= 32 && t - 32 < p.nwait) {
+    const unsigned* flag = p.flags + p.wait[t - 32];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > LANE_WAIT_TIMEOUT_TICKS) {
+        __hip_atomic_store(p.err, (unsigned)p.wait[t - 32] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+    (void)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 namespace {
 struct SegInstr { int op; hipStream_t st; hipEvent_t ev; hipGraphExec_t exec; };   // op 0 launch, 1 record, 2 wait
+struct FlagOf { int f; hipStream_t st; };
 struct SegRec {
   bool dry = false;
+  // mode 2 (flag-synchronised lanes)
+  bool flags_mode = false;
+  unsigned* dflags = nullptr;                // [MAXF] flags, then [MAXL] lane counters (device memory, zeroed)
+  unsigned* herr = nullptr;                  // host-pinned error word
+  int nflags = 0, nwaits = 0, nsignals = 0;
+  std::vector<hipStream_t> lanes;            // index -> stream (its counter is dflags[MAXF + index])
+  std::vector<std::pair<hipEvent_t, FlagOf>> evflag;        // latest record of every needed event
+  std::vector<std::pair<hipStream_t, int>> waited;          // (stream, flag) already waited for in this recording
+  struct Pend { hipStream_t st; std::vector<int> sig, wait; bool bumped; };
+  std::vector<Pend> pend;                                   // per lane: what its next sync kernel carries
+  int nsync = 0;
+  static constexpr int MAXF = 2048, MAXL = 16;
+  Pend& pend_of(hipStream_t st) {
+    for (auto& p : pend) if (p.st == st) return p;
+    pend.push_back(Pend{st, {}, {}, false}); return pend.back();
+  }
+  void begin_capture(hipStream_t st) {
+    if (is_cap(st)) return;
+    const hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { fail("segment begin capture", e); return; }
+    capturing.push_back(st);
+  }
+  // the lane's pending records and waits as one kernel on its capture, in front of whatever is launched on it next
+  void flush(hipStream_t st) {
+    Pend& p = pend_of(st);
+    while (!p.sig.empty() || !p.wait.empty()) {
+      if (lane_of(st) >= MAXL) { fail("too many lanes", hipErrorInvalidValue); return; }
+      begin_capture(st);
+      if (failed) return;
+      LaneSyncP a; memset(&a, 0, sizeof(a));
+      a.flags = dflags; a.ctr = ctr_of(st); a.err = herr; a.bump = p.bumped ? 0 : 1; p.bumped = true;
+      while (a.nsig < LANE_SYNC_MAX && !p.sig.empty()) { a.sig[a.nsig++] = (unsigned short)p.sig.front(); p.sig.erase(p.sig.begin()); }
+      // (waits go out only with the LAST signals: a wait must not precede a record that was made before it)
+      if (p.sig.empty()) while (a.nwait < LANE_SYNC_MAX && !p.wait.empty()) { a.wait[a.nwait++] = (unsigned short)p.wait.front(); p.wait.erase(p.wait.begin()); }
+      hipLaunchKernelGGL(lane_sync_kernel, dim3(1), dim3(64), 0, st, a);
+      ++nsync;
+    }
+  }
+  int lane_of(hipStream_t st) {
+    for (size_t k = 0; k < lanes.size(); ++k) if (lanes[k] == st) return (int)k;
+    lanes.push_back(st); return (int)lanes.size() - 1;
+  }
+  unsigned* ctr_of(hipStream_t st) { return dflags + MAXF + lane_of(st); }
   hipStream_t main = nullptr;
   std::vector<hipEvent_t> needed;            // sorted after the dry pass
   std::vector<hipStream_t> capturing;        // streams with an open segment
@@ -246,10 +330,32 @@ struct SegRec {
     prog.push_back(SegInstr{0, st, nullptr, x});
   }
   void touch(hipStream_t st) {
-    if (dry || is_cap(st)) return;
-    const hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
-    if (e != hipSuccess) { fail("segment begin capture", e); return; }
-    capturing.push_back(st);
+    if (dry) return;
+    if (flags_mode) { flush(st); begin_capture(st); return; }
+    begin_capture(st);
+  }
+  // mode 2: the record of a needed event / a cross-lane wait, collected for the lane's next sync kernel
+  void flag_signal(hipEvent_t ev, hipStream_t st) {
+    if (nflags >= MAXF) { fail("too many cross-lane events", hipErrorInvalidValue); return; }
+    const int f = nflags++;
+    bool found = false;
+    for (auto& p : evflag) if (p.first == ev) { p.second = FlagOf{f, st}; found = true; break; }
+    if (!found) evflag.push_back({ev, FlagOf{f, st}});
+    Pend& p = pend_of(st);
+    // a record made after waits were collected: those waits belong in front of it (flush them first)
+    if (!p.wait.empty()) flush(st);
+    pend_of(st).sig.push_back(f);
+    ++nsignals;
+  }
+  void flag_wait(hipStream_t st, hipEvent_t ev) {
+    const FlagOf* fo = nullptr;
+    for (auto& p : evflag) if (p.first == ev) { fo = &p.second; break; }
+    if (!fo) { fail("wait for an event that was not recorded inside the recording", hipErrorInvalidValue); return; }
+    if (fo->st == st) return;                                   // same lane: stream order
+    for (auto& w : waited) if (w.first == st && w.second == fo->f) return;
+    waited.push_back({st, fo->f});
+    pend_of(st).wait.push_back(fo->f);
+    ++nwaits;
   }
 };
 thread_local SegRec* g_seg = nullptr;
@@ -263,6 +369,7 @@ struct nunet_seg {
   hipStream_t main;
   hipEvent_t ev_in, ev_out;
   int n_launch, n_record, n_wait, n_nodes;
+  unsigned* dflags; unsigned* herr;          // mode 2: flags + lane counters (device), error word (host-pinned)
 };
 
 bool seg_active() { return g_seg != nullptr; }
@@ -270,6 +377,7 @@ bool seg_wait(hipStream_t st, hipEvent_t ev) {
   SegRec* r = g_seg;
   if (!r) return false;
   if (r->dry) { r->needed.push_back(ev); return true; }
+  if (r->flags_mode) { r->flag_wait(st, ev); return true; }
   hipEvent_t e = ev;
   // one wait per (stream, event) between two cuts of the stream is enough
   for (size_t k = r->prog.size(); k-- > 0;) {
@@ -286,6 +394,7 @@ bool seg_record(hipEvent_t ev, hipStream_t st) {
   SegRec* r = g_seg;
   if (!r) return false;
   if (r->dry || !r->is_needed(ev)) return true;
+  if (r->flags_mode) { r->flag_signal(ev, st); return true; }
   // (merging the records lazily - a lane cut only when another lane asks for one of its events - gives 33 instead of 55 segments
   //  per step but 2.64 instead of 2.33 ms: consumers then wait for the producer lane's whole tail; measured, not kept)
   r->cut(st);
@@ -294,11 +403,24 @@ bool seg_record(hipEvent_t ev, hipStream_t st) {
 }
 void seg_touch(hipStream_t st) { if (g_seg) g_seg->touch(st); }
 
-extern "C" int nunet_seg_begin(nunet_stream_t s, int32_t dry) {
+extern "C" int nunet_seg_begin(nunet_stream_t s, int32_t mode) {
   NUNET_REQUIRE(s, "seg_begin: recording needs an explicit (non-default) stream");
   NUNET_REQUIRE(!g_seg && !g_cap.active, "seg_begin: a recording / capture is already active on this thread");
+  NUNET_REQUIRE(mode >= 0 && mode <= 2, "seg_begin: mode %d", mode);
   SegRec* r = new SegRec();
-  r->dry = dry != 0; r->main = (hipStream_t)s;
+  r->dry = mode == NUNET_SEG_DRY; r->main = (hipStream_t)s;
+  if (mode == NUNET_SEG_FLAGS) {
+    r->flags_mode = true;
+    const size_t bytes = sizeof(unsigned) * (SegRec::MAXF + SegRec::MAXL);
+    if (hipMalloc((void**)&r->dflags, bytes) != hipSuccess || hipMemset(r->dflags, 0, bytes) != hipSuccess ||
+        hipHostMalloc((void**)&r->herr, sizeof(unsigned), hipHostMallocDefault) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      nunet_set_error("seg_begin: cannot allocate the lane flags: %s", hipGetErrorString(hipGetLastError()));
+      if (r->dflags) (void)hipFree(r->dflags);
+      delete r;
+      return NUNET_ELAUNCH;
+    }
+    *r->herr = 0u;
+  }
   if (!r->dry) { r->needed = g_seg_needed; std::sort(r->needed.begin(), r->needed.end()); }
   g_seg = r;
   g_dry_run = r->dry;
@@ -318,11 +440,18 @@ extern "C" int nunet_seg_end(nunet_stream_t s, nunet_seg** out) {
     if (out) *out = nullptr;
     return NUNET_OK;
   }
+  if (r->flags_mode) { for (size_t k = 0; k < r->pend.size(); ++k) r->flush(r->pend[k].st); }
   while (!r->capturing.empty()) r->cut(r->capturing.back());
   nunet_seg* G = new nunet_seg();
   G->prog = r->prog; G->graphs = r->graphs; G->execs = r->execs; G->main = r->main; G->ev_in = G->ev_out = nullptr;
+  G->dflags = r->dflags; G->herr = r->herr;
   G->n_launch = G->n_record = G->n_wait = G->n_nodes = 0;
   for (const SegInstr& i : G->prog) { if (i.op == 0) ++G->n_launch; else if (i.op == 1) ++G->n_record; else ++G->n_wait; }
+  if (r->flags_mode) {
+    G->n_record = r->nsignals; G->n_wait = r->nwaits;
+    // the caller's lane is launched first: it heads the dependency order, the others start with a wait for one of its flags
+    for (size_t k = 0; k < G->prog.size(); ++k) if (G->prog[k].st == G->main) { std::swap(G->prog[0], G->prog[k]); break; }
+  }
   for (hipGraph_t g : G->graphs) { size_t n = 0; (void)hipGraphGetNodes(g, nullptr, &n); G->n_nodes += (int)n; }
   const bool failed = r->failed;
   if (failed) nunet_set_error("seg_end: %s", r->err);
@@ -342,9 +471,16 @@ extern "C" int nunet_seg_launch(nunet_seg* G, nunet_stream_t s) {
   NUNET_REQUIRE(G, "seg_launch: null program");
   hipStream_t cs = (hipStream_t)s;
   hipError_t e = hipSuccess;
-  if (cs != G->main) { e = hipEventRecord(G->ev_in, cs); if (e == hipSuccess) e = hipStreamWaitEvent(G->main, G->ev_in, 0); }
+  if (G->herr && *G->herr) {
+    nunet_set_error("seg_launch: a cross-lane wait of an earlier replay timed out (flag %u): two lanes share a hardware queue, or a lane died", *G->herr - 1u);
+    return NUNET_ELAUNCH;
+  }
+  if (cs != G->main || G->dflags) { e = hipEventRecord(G->ev_in, cs); if (e == hipSuccess && cs != G->main) e = hipStreamWaitEvent(G->main, G->ev_in, 0); }
   for (size_t k = 0; k < G->prog.size() && e == hipSuccess; ++k) {
     const SegInstr& i = G->prog[k];
+    // (flag mode: a side lane does not start polling before the caller's earlier work is done)
+    if (i.op == 0 && G->dflags && i.st != G->main) e = hipStreamWaitEvent(i.st, G->ev_in, 0);
+    if (e != hipSuccess) break;
     if (i.op == 0) e = hipGraphLaunch(i.exec, i.st);
     else if (i.op == 1) e = hipEventRecord(i.ev, i.st);
     else e = hipStreamWaitEvent(i.st, i.ev, 0);
@@ -366,5 +502,7 @@ extern "C" void nunet_seg_destroy(nunet_seg* G) {
   for (hipGraph_t g : G->graphs) (void)hipGraphDestroy(g);
   if (G->ev_in) (void)hipEventDestroy(G->ev_in);
   if (G->ev_out) (void)hipEventDestroy(G->ev_out);
+  if (G->dflags) { (void)hipDeviceSynchronize(); (void)hipFree(G->dflags); }
+  if (G->herr) (void)hipHostFree(G->herr);
   delete G;
 }

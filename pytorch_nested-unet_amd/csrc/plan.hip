@@ -599,7 +599,10 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
       // K-split of the weight gradient: the two problems of a block share one launch, the one with fewer input
       // channels takes half the workgroups (fewer, fatter slices: less slab traffic)
       const ConvL& o = cv ? n.c1 : n.c2;
-      c.wg_target = c.cinpad < o.cinpad ? 128 : 256;     // (measured: 64/128, 64/256, 128/512, 256/512 are all slower in the step)
+#ifndef NUNET_WG_MUL
+#define NUNET_WG_MUL 1
+#endif
+      c.wg_target = NUNET_WG_MUL * (c.cinpad < o.cinpad ? 128 : 256);     // (measured: 64/128, 64/256, 128/512, 256/512 are all slower in the step)
       nunet_wgrad_desc wd; memset(&wd, 0, sizeof(wd));
       wd.N = cfg->N; wd.H = P->hl[n.i]; wd.W = P->wl[n.i]; wd.C0 = c.cinpad; wd.Cout = c.cout; wd.target_wgs = c.wg_target; wd.max_slabs = ks_max;
       c.ks = nunet_conv3x3_wgrad_slabs(&wd);
@@ -948,7 +951,9 @@ static void seg_pick_lanes(PlanRt* rt, hipStream_t main_s) {
     if (ok) { pick[np++] = cand[k]; usedc[k] = true; }
   }
   for (int k = 0; k < nc; ++k) if (!usedc[k]) (void)hipStreamDestroy(cand[k]);
-  for (int q = 0; q < 3; ++q) rt->seg_lanes[q] = q < np ? pick[q] : (np > 0 ? pick[q % np] : rt->lanes[q + 1]);
+  // (fewer than three distinct queues found: lanes share a STREAM - never two streams of one queue, which the flag-synchronised
+  //  program could not survive: a polling kernel ahead of its signal in the same queue)
+  for (int q = 0; q < 3; ++q) rt->seg_lanes[q] = q < np ? pick[q] : (np > 0 ? pick[q % np] : main_s);
   rt->seg_lanes_distinct = np;
   if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (eb) (void)hipEventDestroy(eb);
 }
@@ -1012,7 +1017,10 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
       else for (int q = 0; q < 3; ++q) rt->seg_lanes[q] = rt->lanes[q + 1];
     }
     for (int q = 0; q < 3; ++q) lane_s[q + 1] = rt->seg_lanes[q];
-    lane_s[4] = lane_s[3];
+    // (the deferred weight gradients of the chain blocks go to the stream of lane 1: its own block, x0_1, is the LAST of the
+    //  level-0 row's backward chain B04 -> B03 -> B02 -> B01, so that stream idles for the first 500 us of the backward pass; on
+    //  lane 3's stream they sat in front of B03 and held the whole row back by 280 us)
+    lane_s[4] = lane_s[1];
   }
   if (multi) {
     fork_ev = new_event();

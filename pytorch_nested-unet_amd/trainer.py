@@ -54,7 +54,9 @@ class TrainStep:
         if self.schedule not in ("lanes", "wave"):
             raise L.NunetError("TrainStep: schedule %r is not 'lanes' or 'wave'" % (self.schedule,))
         L.check(L.lib().nunet_plan_set_schedule(self.pl.handle, 1 if self.schedule == "wave" else 0), "plan_set_schedule")
-        self.segmented = (os.environ.get("NUNET_SEGMENTED", "0") == "1") if segmented is None else bool(segmented)
+        if segmented is None:
+            segmented = {"0": False, "1": True, "2": "flags", "flags": "flags"}.get(os.environ.get("NUNET_SEGMENTED", "0"), False)
+        self.segmented = segmented
         self.heads = self.pl.heads
         self.x = x0
         self.t = torch.zeros((n, self.ncls, h, w), dtype=torch.float32, device=dev)
@@ -338,7 +340,7 @@ class TrainStep:
             # dependencies as events between graph launches (csrc/graph.hip nunet_seg_*: explicit node -> queue placement on lanes
             # chosen by measurement; 2.33 vs 1.91 ms per step on MI355X: every segment launch costs 10-13 us on its lane)
             body = lambda: (self._fwd_bwd(), self._opt())
-            self.g_fb = _SegProgram(s, body) if self.segmented else _NativeGraph(s, body)
+            self.g_fb = _SegProgram(s, body, flags=self.segmented == "flags") if self.segmented else _NativeGraph(s, body)
         else:
             if self.dp_auto:
                 self._choose_layout(s)
@@ -479,14 +481,15 @@ class _SegProgram:
     """nunet_seg_* wrapper with the replay() surface of torch.cuda.CUDAGraph: the step body is run twice on `side_stream` - a dry
     pass that launches nothing and finds the cross-lane events, then the recording pass."""
 
-    def __init__(self, side_stream, body):
+    def __init__(self, side_stream, body, flags=False):
         import ctypes as C
         lib = L.lib()
         self.stream = side_stream            # the program replays on this stream: keep it alive
         self.handle = None
+        self.flags = bool(flags)
         with torch.cuda.stream(side_stream):
-            for dry in (1, 0):
-                L.check(lib.nunet_seg_begin(L.stream(), dry), "seg_begin")
+            for mode in (1, 2 if flags else 0):      # NUNET_SEG_DRY, then NUNET_SEG_FLAGS / NUNET_SEG_RECORD
+                L.check(lib.nunet_seg_begin(L.stream(), mode), "seg_begin")
                 try:
                     body()
                 finally:

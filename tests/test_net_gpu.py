@@ -715,24 +715,37 @@ def test_segmented_step_program_equals_the_single_graph(synth):
     sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, True).state_dict().items()}
     batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=300 + k) for k in range(3)]
     outs = []
-    for seg in (False, True):
+    for seg in (False, True, "flags"):
         m = nunet_amd.archs.NestedUNet(1, 3, True, dtype="bf16")
         m.load_state_dict(sd)
         m = m.to(DEV).train()
         ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, segmented=seg)
         ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
-        assert isinstance(ts.g_fb, _SegProgram) == seg
+        assert isinstance(ts.g_fb, _SegProgram) == bool(seg)
         if seg:
             info = ts.g_fb.info()
-            print("segmented program:", info)
-            assert info["graph_launches"] > 4 and info["event_waits"] >= info["event_records"] > 0 and info["kernel_nodes"] > 100
-        for img, msk in batches:
-            ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+            print("segmented program (%s):" % seg, info)
+            assert info["event_waits"] >= info["event_records"] > 0 and info["kernel_nodes"] > 100
+            # flag-synchronised lanes: ONE single-stream graph per lane; event mode: a graph per segment between two cuts
+            assert (1 <= info["graph_launches"] <= 4) if seg == "flags" else info["graph_launches"] > 4
+        for rep in range(8 if seg == "flags" else 1):       # (the flag program replays the same three batches: a race would not repeat)
+            if rep:
+                ts.eng.flat_params.copy_(p0); ts.mom.copy_(m0); ts.eng.bnbuf.copy_(b0)
+            else:
+                p0, m0, b0 = ts.eng.flat_params.clone(), ts.mom.clone(), ts.eng.bnbuf.clone()
+            for img, msk in batches:
+                ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+            torch.cuda.synchronize()
+            if rep:
+                assert all(torch.equal(a, b) for a, b in zip(first, (ts.eng.flat_params, ts.mom, ts.eng.bnbuf, ts.loss_out))), rep
+            else:
+                first = [t.clone() for t in (ts.eng.flat_params, ts.mom, ts.eng.bnbuf, ts.loss_out)]
         torch.cuda.synchronize()
-        outs.append([t.clone() for t in (ts.eng.flat_params, ts.mom, ts.eng.bnbuf, ts.loss_out)])
+        outs.append(first)
         del ts, m
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])

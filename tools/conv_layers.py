@@ -39,6 +39,8 @@ def time_graph(fn):
 def conv(H, c0, c1, cout, lt=0, bnr=False, d1=0, ws=None):
     d = L.ConvDesc()
     d.dtype = dt; d.N = N; d.H = H; d.W = H
+    tl = int(os.environ.get("TILE", "0"))
+    d.tile = tl if (tl not in (2, 4) or cout % 64 == 0) else 0
     s0 = t(N, H, H, c0); d.src0 = L.ptr(s0).value; d.C0 = c0; d.P0 = c0
     if c1:
         s1 = t(N, H, H, c1); d.src1 = L.ptr(s1).value; d.C1 = c1; d.P1 = c1
@@ -74,9 +76,10 @@ def conv(H, c0, c1, cout, lt=0, bnr=False, d1=0, ws=None):
     return time_graph(lambda: L.check(L.lib().nunet_conv3x3_fwd(C.byref(d), L.stream())))
 
 ONLY = os.environ.get("ONLY")   # "i,j,k": level, column, kind (0 conv1, 1 conv2, 2 dgrad2, 3 dgrad1) - one case, R*13 eager-ish launches (for PC sampling)
-print("%-8s %10s %10s %10s %10s   (us per launch, bf16 N=%d %dx%d)" % ("block", "conv1", "conv2", "dgrad2", "dgrad1", N, HW, HW))
+print("%-8s %10s %10s %10s %10s   (us per launch | TFLOP/s, bf16 N=%d %dx%d, TILE=%s)" % ("block", "conv1", "conv2", "dgrad2", "dgrad1", N, HW, HW, os.environ.get("TILE", "0")))
+MAXLEV = int(os.environ.get("MAXLEV", "5"))
 tot = [0.0] * 4
-for i in range(5):
+for i in range(min(5, MAXLEV)):
     H = HW >> i; f = NBF[i]
     ws = torch.zeros(8 * N * H * H * (5 * f), device="cuda") if i >= 3 else None
     for j in range(5 - i):
@@ -128,6 +131,8 @@ for i in range(5):
             dd = 0.0
         else:
             dd = conv(H, f, 0, c0 + c1, lt=2, d1=c1, ws=ws)
-        print("B%d%d      %10.1f %10.1f %10.1f %10.1f" % (i, j, a, b, c, dd))
+        fl = lambda cin, cout, us: 2.0 * 9 * cin * cout * N * H * H / (us * 1e6) if us > 0 else 0.0
+        print("B%d%d      %10.1f %10.1f %10.1f %10.1f   | %6.0f %6.0f %6.0f %6.0f" % (i, j, a, b, c, dd, fl(c0 + c1, f, a), fl(f, f, b), fl(f, f, c), fl(f, c0 + c1, dd)))
+        keep.clear(); torch.cuda.empty_cache()
         for k, v in enumerate((a, b, c, dd)): tot[k] += v
 if not ONLY: print("sum      %10.1f %10.1f %10.1f %10.1f   total %.1f" % (*tot, sum(tot)))
