@@ -937,8 +937,12 @@ static void conv_setup(const nunet_conv_desc* d, ConvSetup& S) {
   p.nch0 = p.C0 / C::KC;
   p.nch = p.nch0 + p.C1 / C::KC;
   // (measured on the 96x96 workload, tools/conv_layers.py: below ~60 items a split pays for its finalize launch, above it does not)
-  if (d->splitk_ws && items <= 60 && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
-    int Sn = (int)((320 + items - 1) / items);
+#ifndef NUNET_SK_ITEMS
+#define NUNET_SK_ITEMS 60
+#define NUNET_SK_TARGET 320
+#endif
+  if (d->splitk_ws && items <= NUNET_SK_ITEMS && p.nch >= 8 && p.Cout <= 1024 && (256 / (p.Cout / C::EPV)) >= 1) {
+    int Sn = (int)((NUNET_SK_TARGET + items - 1) / items);
     if (Sn > p.nch / 2) Sn = p.nch / 2;
     const long long need = (long long)Sn * d->N * d->H * d->W * p.Cout;
     if (Sn > 1 && need <= d->splitk_ws_floats) {
@@ -1026,7 +1030,10 @@ static int conv_cfg_of(const nunet_conv_desc* d) {
   if (d->tile >= 1 && d->tile <= 4) return d->tile - 1;
   const long px = (long)d->N * d->H * d->W;
   const long items_std = cout % 64 == 0 ? ceil_div64(px, 128) * (cout / 64) : ceil_div64(px, 256) * (cout / 32);
-  const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD);
+  // (256x256 bs32, tools/conv_layers.py with nunet_conv_desc.tile: with >= 1M pixels the 256-pixel tile wins for every Cout = 32
+  //  layer - 8 or more items per resident workgroup, no round quantisation left, the weight stage shared by twice the pixels:
+  //  level-0 conv1 -13 %, conv2 -3 %)
+  const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD && px < (1L << 20));
   if (small) return 0;
   return cout % 64 == 0 ? 1 : 2;
 }

@@ -489,7 +489,7 @@ struct nunet_plan {
   size_t off_img;
   size_t X[5], GX[5];
   size_t off_dy[16][2], off_da1[16], off_gup[16], off_gpin[16];   // per-BLOCK backward scratch (dY ping-pong), so blocks of one level can run on different lanes
-  size_t off_sk[5]; long long sk_floats[5];   // per-level fp32 K-split slabs (levels 3, 4)   // per-level backward scratch (dY ping-pong)
+  size_t off_sk[16]; long long sk_floats[16];   // per-BLOCK fp32 K-split slabs (blocks of the grid-starved levels; 0: none)   // per-level backward scratch (dY ping-pong)
   struct PlanRt* rt;
   size_t total;
   PackTab ptab; long long pack_maxn;
@@ -599,10 +599,11 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
       // K-split of the weight gradient: the two problems of a block share one launch, the one with fewer input
       // channels takes half the workgroups (fewer, fatter slices: less slab traffic)
       const ConvL& o = cv ? n.c1 : n.c2;
-#ifndef NUNET_WG_MUL
-#define NUNET_WG_MUL 1
-#endif
-      c.wg_target = NUNET_WG_MUL * (c.cinpad < o.cinpad ? 128 : 256);     // (measured: 64/128, 64/256, 128/512, 256/512 are all slower in the step)
+      // (96x96 bs16, measured: 64/128, 64/256, 128/512, 256/512 are all slower in the step. 256x256 bs32: twice the workgroups are
+      //  24 % faster alone - 4.34 -> 3.29 ms over the 15 launches - and +2.3 % on the step: with 7 x the pixels per slice the
+      //  slices are long enough to amortise a workgroup's start and the K-split slabs stay small beside the tensors read)
+      const int wg_mul = (long long)cfg->N * cfg->H * cfg->W >= (1LL << 20) ? 2 : 1;
+      c.wg_target = wg_mul * (c.cinpad < o.cinpad ? 128 : 256);
       nunet_wgrad_desc wd; memset(&wd, 0, sizeof(wd));
       wd.N = cfg->N; wd.H = P->hl[n.i]; wd.W = P->wl[n.i]; wd.C0 = c.cinpad; wd.Cout = c.cout; wd.target_wgs = c.wg_target; wd.max_slabs = ks_max;
       c.ks = nunet_conv3x3_wgrad_slabs(&wd);
@@ -644,13 +645,17 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
     P->off_gup[k] = bump(cur, i < 4 ? (size_t)P->px[i] * NBF[i + 1] * P->es : 256);
     P->off_gpin[k] = bump(cur, i > 0 ? (size_t)P->px[i] * NBF[i - 1] * P->es : 256);
   }
-  // K-split slabs for the grid-starved levels 3 and 4 (up to 8 slices of the widest output at the
-  // level); deterministic (fixed summation order). Measured +1.2 % on the bench; NUNET_SPLITK=0 disables.
-  const bool sk_on = true;
-  for (int i = 0; i < 5; ++i) {
-    const int maxc = (i < 3 || !sk_on) ? 0 : (i < 4 ? (4 - i) * NBF[i] + NBF[i + 1] : NBF[4]);
-    P->sk_floats[i] = 8LL * P->px[i] * maxc;   // up to 8 slabs
-    P->off_sk[i] = bump(cur, (size_t)P->sk_floats[i] * 4 + 16);
+  // K-split slabs for the blocks of the grid-starved levels (up to 8 slices of the block's widest conv output, the input
+  // gradient of conv1); deterministic (fixed summation order). One buffer per BLOCK: the four convs of a block follow each
+  // other anyway, and blocks of one level on different lanes must not serialise on a shared scratch.
+#ifndef NUNET_SK_MINLEV
+#define NUNET_SK_MINLEV 3
+#endif
+  for (size_t k = 0; k < P->exec.size() && k < 16; ++k) {
+    const Node& n = P->exec[k];
+    const int maxc = n.i < NUNET_SK_MINLEV ? 0 : (n.c1.cinpad > n.c1.cout ? n.c1.cinpad : n.c1.cout);
+    P->sk_floats[k] = 8LL * P->px[n.i] * maxc;   // up to 8 slabs
+    P->off_sk[k] = bump(cur, (size_t)P->sk_floats[k] * 4 + 16);
   }
   P->total = align_up(cur, 256);
 
@@ -756,7 +761,7 @@ static inline char* AB(void* arena, size_t off) { return (char*)arena + off; }
 // per-buffer tracker (last-writer event, last-reader event per lane). Captured by the
 // caller, the lanes become parallel branches of ONE hipGraph.
 // ---------------------------------------------------------------------------
-#define NRES 480
+#define NRES 496
 enum { R_X = 0, R_GX = 25, R_BLK = 50, R_LVL = 330, R_IMG = 230, R_LOGITS = 231, R_DLOGITS = 232, R_WP = 233, R_GS = 238, R_SK = 470, R_GSW = 240, R_GSV = 280 };
 enum { B_Y1 = 0, B_A1, B_Y2, B_UP, B_PIN, B_ST1, B_ST2, B_STRIDE = 8 };
 enum { L_DY0 = 0, L_DY1, L_DA1, L_GUP, L_GPIN, L_STRIDE = 8 };
@@ -927,7 +932,18 @@ static void seg_pick_lanes(PlanRt* rt, hipStream_t main_s) {
   const int NC = 12, SPIN_US = 100;
   hipStream_t cand[NC];
   int nc = 0;
-  for (int k = 0; k < NC; ++k) if (hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking) == hipSuccess) ++nc; else (void)hipGetLastError();
+  // the side lanes get the LOWEST stream priority: the chain lane's workgroups are dispatched ahead of theirs (+1.4 % on the
+  // flag-synchronised step; NUNET_SIDE_PRIO=0: default priority)
+  static int side_prio = -1;
+  if (side_prio < 0) { const char* e = getenv("NUNET_SIDE_PRIO"); side_prio = e ? atoi(e) : 1; }
+  int pr_least = 0, pr_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+  // (measured and not kept: side lanes on CU-masked streams - hipExtStreamCreateWithCUMask, 16 to 96 CUs kept free for the chain -
+  //  and the chain on a high-priority stream both run the step at 5.3 ms instead of 1.85)
+  for (int k = 0; k < NC; ++k) {
+    const hipError_t ce = side_prio ? hipStreamCreateWithPriority(&cand[nc], hipStreamNonBlocking, pr_least) : hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking);
+    if (ce == hipSuccess) ++nc; else (void)hipGetLastError();
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreateWithFlags(&eb, hipEventDisableTiming);
   auto overlap = [&](hipStream_t a, hipStream_t b) {          // true: a and b run side by side
@@ -1166,7 +1182,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
     const int lane = lane_of(P, n), rb = R_BLK + (int)k * B_STRIDE;
-    const int rskf = P->sk_floats[i] > 0 ? R_SK + i : -1;
+    const int rskf = P->sk_floats[k] > 0 ? R_SK + (int)k : -1;
     if (n.up_slot >= 0) {
       S.name("B%d%d.upF", n.i, n.j);
       S.add(lane, 0, 7.f, {R_X + (i + 1) * 5 + n.up_slot}, {rb + B_UP}, [=](hipStream_t ls) {
@@ -1183,7 +1199,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       d.bias = nullptr;  // absorbed by the BatchNorm that follows (bn_stat_coeffs)
       d.dst0 = AB(arena, n.y1); d.D0 = f; d.Q0 = f;
       d.stats = training ? (int64_t*)fx_of(arena, P, 0, L.stats) : nullptr;
-      if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
+      if (P->sk_floats[k] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[k]); d.splitk_ws_floats = P->sk_floats[k]; }
       const int alg_cin = (i == 0 && n.in_prefix == 0) ? c.input_channels : 0;
       S.name("B%d%d.conv1", n.i, n.j);
       if (n.in_prefix == 0) {
@@ -1212,7 +1228,7 @@ extern "C" int nunet_plan_forward(nunet_plan* P, const float* params, float* bnb
       d.wpack = wpack + (size_t)L.wf * es;
       d.dst0 = AB(arena, n.y2); d.D0 = f; d.Q0 = f;
       d.stats = training ? (int64_t*)fx_of(arena, P, 0, L.stats) : nullptr;
-      if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
+      if (P->sk_floats[k] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[k]); d.splitk_ws_floats = P->sk_floats[k]; }
       S.name("B%d%d.conv2", n.i, n.j);
       S.add_conv(lane, {rb + B_Y1, rb + B_ST1, R_WP + i}, {rb + B_Y2, rb + B_ST2, rb + B_A1, rskf}, d);
     }
@@ -1625,7 +1641,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     const Node& n = P->exec[k];
     const int i = n.i, f = NBF[i], H = P->hl[i], W = P->wl[i];
     const int lane = lane_of(P, n), wlane = 5 + lane, rb = R_BLK + k * B_STRIDE, rl = R_LVL + k * L_STRIDE;
-    const int rsk = P->sk_floats[i] > 0 ? R_SK + i : -1;
+    const int rsk = P->sk_floats[k] > 0 ? R_SK + k : -1;
     if (!written[i][n.out_slot]) { nunet_set_error("plan_backward: internal: grad of x%d_%d never produced", n.i, n.j); rc = NUNET_EINVAL; break; }
     if (spin_us > 0 && k == k_split - 1 && (phases & 2)) {
       const int us = spin_us;
@@ -1672,7 +1688,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       d.dst0 = da1; d.D0 = f; d.Q0 = f;
       d.bn_y = AB(arena, n.y1); d.bn_py = f; d.bn_mean_invstd = save + L1.save;
       d.bn_gamma = params + L1.g_off; d.bn_beta = params + L1.be_off; d.bn_sums = (int64_t*)fx_of(arena, P, 1, L1.bsum);
-      if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
+      if (P->sk_floats[k] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[k]); d.splitk_ws_floats = P->sk_floats[k]; }
       S.name("B%d%d.dgrad2", n.i, n.j);
       S.add_conv(lane, {r_gxo, rb + B_Y2, rb + B_Y1, R_WP + i}, {r_dy2, r_da1, r_v2, r_v1, rsk}, d);
     }
@@ -1687,7 +1703,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       d.tf_dbias = gv1; d.tf_dgamma = gv1 + L1.cout; d.tf_dbeta = gv1 + 2 * L1.cout;
       d.tf_store = dy1; d.tf_ps = f;
       d.wpack = wpack + (size_t)L1.wd * es;
-      if (P->sk_floats[i] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[i]); d.splitk_ws_floats = P->sk_floats[i]; }
+      if (P->sk_floats[k] > 0) { d.splitk_ws = (float*)AB(arena, P->off_sk[k]); d.splitk_ws_floats = P->sk_floats[k]; }
       S.name("B%d%d.dgrad1", n.i, n.j);
       if (n.in_prefix == 0) {
         d.dst0 = AB(arena, P->off_gpin[k]); d.D0 = NBF[i - 1]; d.Q0 = NBF[i - 1];
