@@ -396,7 +396,12 @@ int nunet_plan_set_multistream(nunet_plan* p, int32_t enable);
  * NUNET_SCHEDULE_WAVE: ONE stream, dependency order from a critical-path list scheduler, every ready 3x3 convolution of the same
  * kernel variant grouped into one launch - a single-stream graph (ROCm replays those as one batch of pre-built packets) whose
  * concurrency lives inside the launches. Bit-identical results; set before the first forward / capture. */
-enum { NUNET_SCHEDULE_LANES = 0, NUNET_SCHEDULE_WAVE = 1 };
+/* NUNET_SCHEDULE_LIST: the lane of every op is chosen by a list scheduler over the hazard graph of the program order (critical-path
+ * priority, earliest start in a simulation with per-op costs) instead of following the op's block; meant for lanes that are real
+ * in-order streams (NUNET_SEG_FLAGS). nunet_plan_calibrate(p, 1) ... one captured step replayed on one lane ...
+ * nunet_plan_calibrate(p, 0) replaces the built-in cost estimates by the measured isolated cost of every op. */
+enum { NUNET_SCHEDULE_LANES = 0, NUNET_SCHEDULE_WAVE = 1, NUNET_SCHEDULE_LIST = 2 };
+int nunet_plan_calibrate(nunet_plan* p, int32_t begin);
 int nunet_plan_set_schedule(nunet_plan* p, int32_t schedule);
 /* debug/test access to an intermediate: name like "x0_0", "x2_1" (block
  * outputs, NHWC). Returns byte offset into arena; fills pitch/channels. */

@@ -13,6 +13,8 @@
 #include <functional>
 #include <algorithm>
 
+#include <map>
+#include <string>
 #include <vector>
 #include <string>
 #include <stdarg.h>
@@ -456,6 +458,8 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   // NUNET_STAMPS=1 diagnostic: a 1-thread kernel after every scheduled op writes the 100 MHz wall clock,
   // so the real timeline of an (unprofiled) hipGraph replay can be read back (tools/stamp_timeline.py)
   unsigned long long* stamps;              // device, [2][STAMP_CAP]
+  int calibrating;                         // nunet_plan_calibrate: single lane + stamps, to measure every op's isolated cost
+  std::map<std::string, float> op_cost[2]; // measured cost (us) by op name, per pass; empty: the built-in estimates
   hipEvent_t b0_event;                     // recorded when the first gradient bucket (phase-1 nodes + heads) is complete
   bool b0_enabled;
   int seg_lanes_distinct;                  // how many of them were measured to run beside the caller's stream and each other
@@ -692,6 +696,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->lanes_external = false;
   rt->cap_next = 0;
   rt->stamps = nullptr;
+  rt->calibrating = 0;
   rt->b0_event = nullptr; rt->b0_enabled = false; rt->open_sched = nullptr;
   rt->seg_lanes[0] = rt->seg_lanes[1] = rt->seg_lanes[2] = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
@@ -882,20 +887,31 @@ struct Sched {
     for (int x : rd) if (x >= 0) { if (o.nrd < 12) o.rd[o.nrd++] = x; else failed = true; }
     for (int x : wr) if (x >= 0) { if (o.nwr < 8) o.wr[o.nwr++] = x; else failed = true; }
     memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
+    measured_cost(o);
     o.fn = std::move(fn);
     ops.push_back(std::move(o));
+  }
+  // the op's isolated cost as nunet_plan_calibrate measured it (by name), instead of the built-in estimate
+  void measured_cost(Op& o) {
+    const std::map<std::string, float>& m = rt->op_cost[pass & 1];
+    if (m.empty() || !o.name[0]) return;
+    const auto it = m.find(o.name);
+    if (it != m.end()) o.cost = it->second;
   }
   void add_v(int lane, int leaf, float cost, const int* rd, int nrd, std::function<int(hipStream_t)> fn) {
     Op o; o.lane = lane_map[lane]; o.leaf = leaf; o.cost = cost; o.nrd = o.nwr = 0; o.kind = K_GEN; o.alg_cin = 0;
     for (int q = 0; q < nrd; ++q) if (rd[q] >= 0) { if (o.nrd < 12) o.rd[o.nrd++] = rd[q]; else failed = true; }
     memcpy(o.name, cur_name, sizeof(o.name)); cur_name[0] = 0;
+    measured_cost(o);
     o.fn = std::move(fn);
     ops.push_back(std::move(o));
   }
   int run_ops();
   int run_wave();
+  int run_list();
   bool wave;                           // single-stream schedule: no lanes, no events; run() picks
-  int run() { return wave ? run_wave() : run_ops(); }
+  bool list;                           // lanes assigned by a list scheduler over the dependency graph (run_list) instead of by block
+  int run() { return wave ? run_wave() : (list && multi) ? run_list() : run_ops(); }
   void end() {
     if (!multi) { stamp(main_s, 0); cur_name[0] = 0; return; }
     hipStream_t st = lane_s[cur_lane];
@@ -991,8 +1007,9 @@ void Sched::init(nunet_plan* P, hipStream_t s, int pass_) {
     rt->stamp_labels[pass].clear();
     if (rt->stamps) { snprintf(cur_name, sizeof(cur_name), "start"); stamp(s, 0); cur_name[0] = 0; }
   }
-  multi = rt->multistream != 0 && rt->lanes_ok;
-  wave = rt->wave != 0;
+  multi = rt->multistream != 0 && rt->lanes_ok && !rt->calibrating;
+  wave = rt->wave == 1 && !rt->calibrating;
+  list = rt->wave == 2 && !rt->calibrating;
   if (wave) multi = false;             // one stream: no lanes to fork, no events
   failed = false;
   capturing = false;
@@ -1052,6 +1069,95 @@ int Sched::run_ops() {
   for (size_t q = 0; q < ops.size() && rc == NUNET_OK; ++q) {
     Op& o = ops[q];
     hipStream_t st = begin_v(o.lane, o.rd, o.nrd, o.wr, o.nwr);
+    rc = o.fn(st);
+    memcpy(cur_name, o.name, sizeof(cur_name));
+    end();
+  }
+  ops.clear();
+  return rc;
+}
+
+// List schedule: the lane of every op is CHOSEN here instead of following its block. The hazards of the program order (read after
+// write, write after write - the accumulation order into the shared gradient slots -, write after read) are the edges of a DAG;
+// ops are taken by critical-path priority (cost + longest path to the end) and each goes to the lane on which it can start
+// earliest in a simulation with the ops' cost estimates (a dependency that crosses lanes costs XSYNC), then issued in simulated
+// start order. Any topological order of that DAG keeps every conflicting pair in program order, so the resource tracker sees
+// the same hazards and the results are bit-identical to the block-lane schedule (tests assert it). Meant for lanes that are
+// real in-order streams (the flag-synchronised program), where the issue order on a lane IS its execution order: the
+// block-lane order put leaf work (weight gradients) in front of critical ops of the same lane.
+int Sched::run_list() {
+  const int n = (int)ops.size();
+  constexpr int NLMAX = 4;
+  // three lanes: measured on MI355X (96x96 bs16, flag-synchronised lanes) 2 / 3 / 4 lanes = 8640 / 9270 / 8950 images/s - the fourth
+  // concurrent stream costs the critical chain more than its overlap buys; limiting the summed chip share of the concurrent ops
+  // instead (a capacity model over the launch grids) only lost: 1.5 / 2.0 / 2.5 / 3.0 full-chip ops at once = 6610 / 8480 / 8720 /
+  // 9260. A crossing dependency costs one sync kernel on each side (XSYNC; 0 / 3 / 10 us in the model: no difference).
+  static int NL = 0; static float XSYNC = 3.f;
+  if (!NL) { const char* e = getenv("NUNET_LIST_LANES"); NL = e ? atoi(e) : 3; if (NL < 1 || NL > NLMAX) NL = 3; }
+  std::vector<std::vector<int>> succ(n), pred(n);
+  std::vector<int> indeg(n, 0);
+  {
+    std::vector<int> lastw(NRES, -1);
+    std::vector<std::vector<int>> readers(NRES);
+    auto edge = [&](int a, int b) { if (a >= 0 && a != b && std::find(succ[a].begin(), succ[a].end(), b) == succ[a].end()) { succ[a].push_back(b); pred[b].push_back(a); ++indeg[b]; } };
+    for (int i = 0; i < n; ++i) {
+      const Op& o = ops[i];
+      for (int q = 0; q < o.nrd; ++q) edge(lastw[o.rd[q]], i);
+      for (int q = 0; q < o.nwr; ++q) { edge(lastw[o.wr[q]], i); for (int r : readers[o.wr[q]]) edge(r, i); }
+      for (int q = 0; q < o.nrd; ++q) readers[o.rd[q]].push_back(i);
+      for (int q = 0; q < o.nwr; ++q) { lastw[o.wr[q]] = i; readers[o.wr[q]].clear(); }
+    }
+  }
+  std::vector<float> prio(n, 0.f), tend(n, 0.f);
+  for (int i = n - 1; i >= 0; --i) { float m = 0.f; for (int s : succ[i]) m = std::max(m, prio[s]); prio[i] = ops[i].cost + m; }
+  std::vector<int> ready, lane(n, 0), order;
+  float lane_free[NLMAX] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < n; ++i) if (indeg[i] == 0) ready.push_back(i);
+  // event-driven: the lane that falls idle first takes the most urgent op that could start on it by then; when nothing could, the
+  // lane's clock moves on to the next moment something can (so leaf work fills the holes of a lane instead of queueing at its end)
+  auto est = [&](int p, int l) { float t = 0.f; for (int q : pred[p]) t = std::max(t, tend[q] + (lane[q] != l ? XSYNC : 0.f)); return t; };
+  int guard = 0;
+  while (!ready.empty() && guard++ < 100000) {
+    int l = 0;
+    for (int k = 1; k < NL; ++k) if (lane_free[k] < lane_free[l]) l = k;
+    const float T = lane_free[l];
+    int best = -1;
+    for (int q = 0; q < (int)ready.size(); ++q) {
+      if (est(ready[q], l) > T + 0.01f) continue;
+      if (best < 0 || prio[ready[q]] > prio[ready[best]] || (prio[ready[q]] == prio[ready[best]] && ready[q] < ready[best])) best = q;
+    }
+    if (best < 0) {
+      // nothing can start on this lane yet: wait for the earliest of (an op becoming startable here, another lane falling idle)
+      float nt = 1e30f;
+      for (int q : ready) nt = std::min(nt, est(q, l));
+      for (int k = 0; k < NL; ++k) if (k != l && lane_free[k] > T) nt = std::min(nt, lane_free[k]);
+      lane_free[l] = nt > T ? nt : T + 0.5f;
+      continue;
+    }
+    const int p = ready[best];
+    ready.erase(ready.begin() + best);
+    lane[p] = l; tend[p] = T + ops[p].cost; lane_free[l] = tend[p];
+    order.push_back(p);
+    for (int s2 : succ[p]) if (--indeg[s2] == 0) ready.push_back(s2);
+  }
+  int rc = NUNET_OK;
+  if ((int)order.size() != n) { nunet_set_error("plan: list schedule placed %d of %d ops (dependency cycle)", (int)order.size(), n); rc = NUNET_EINVAL; }
+  // issue in simulated start order (stable: a topological order of the hazard DAG)
+  std::vector<int> idx(order);
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return tend[a] - ops[a].cost < tend[b] - ops[b].cost; });
+  // (the sort by start time keeps predecessors first: a successor starts at or after its predecessor's end)
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("NUNET_LIST_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg && !g_dry_run) {
+      float mk = 0.f; for (int i = 0; i < n; ++i) mk = std::max(mk, tend[i]);
+      fprintf(stderr, "list schedule pass %d: %d ops, simulated makespan %.1f us, critical path %.1f us%s\n", pass, n, mk, n ? prio[0] : 0.f, rt->op_cost[pass & 1].empty() ? " (built-in costs)" : " (measured costs)");
+      if (dbg > 1) for (int i : idx) fprintf(stderr, "  %8.1f %6.1f  L%d %s\n", tend[i] - ops[i].cost, ops[i].cost, lane[i], ops[i].name);
+    }
+  }
+  for (size_t q = 0; q < idx.size() && rc == NUNET_OK; ++q) {
+    Op& o = ops[idx[q]];
+    hipStream_t st = begin_v(lane[idx[q]], o.rd, o.nrd, o.wr, o.nwr);
     rc = o.fn(st);
     memcpy(cur_name, o.name, sizeof(cur_name));
     end();
@@ -1769,7 +1875,7 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
       // back until the chain reaches the deep levels (B31 ..., grid-starved kernels that leave most CUs idle): they run
       // on lane 4 behind a dependency on the gradient that B22's upsample-backward hands to B31
       int wl = wlane, r_gate = -1;     // (measured +1.9 % on the step)
-      if (!P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3 && !S.wave) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
+      if (!P->cfg.unet && n.j > 0 && n.i + n.j == 4 && n.i <= 2 && (phases & 3) == 3 && !S.wave && !S.list) { wl = 4; r_gate = R_GX + 3 * 5 + 1; }
       const float wcost = 8.f + (float)(2.0 * 9 * ((double)L1.cinpad + L2.cinpad) * f * (double)c.N * H * W / 3.5e8);
       S.add(wl, 1, wcost, {rb + B_A1, r_dy2, r_dy1, r_in, rx[0], rx[1], rx[2], rx[3], r_up, r_gate}, {R_GSW + 2 * k, R_GSW + 2 * k + 1},
             [=](hipStream_t ls) {
@@ -1880,6 +1986,46 @@ extern "C" int nunet_plan_stamps_read(nunet_plan* P, int32_t pass, uint64_t* tic
   return NUNET_OK;
 }
 
+// Calibration of the list scheduler: between begin = 1 and begin = 0 every pass runs on ONE lane with a device timestamp behind
+// every op (capture one step into a graph, replay it a few times, synchronise); begin = 0 turns the stamps into the isolated cost
+// of every op (by name: "B04.dgrad1" ...), which later passes use instead of the built-in estimates.
+extern "C" int nunet_plan_calibrate(nunet_plan* P, int32_t begin) {
+  NUNET_REQUIRE(P, "plan_calibrate: null plan");
+  PlanRt* rt = rt_of(P);
+  if (begin) {
+    if (!rt->stamps && hipMalloc((void**)&rt->stamps, 2 * STAMP_CAP * sizeof(unsigned long long)) != hipSuccess) {
+      (void)hipGetLastError(); rt->stamps = nullptr;
+      nunet_set_error("plan_calibrate: cannot allocate the stamp buffer"); return NUNET_ELAUNCH;
+    }
+    rt->calibrating = 1;
+    return NUNET_OK;
+  }
+  NUNET_REQUIRE(rt->calibrating && rt->stamps, "plan_calibrate: end without begin");
+  rt->calibrating = 0;
+  int rc = NUNET_OK;
+  if (hipDeviceSynchronize() != hipSuccess) { nunet_set_error("plan_calibrate: synchronise failed"); rc = NUNET_ELAUNCH; }
+  for (int pass = 0; pass < 2 && rc == NUNET_OK; ++pass) {
+    const std::vector<std::string>& lab = rt->stamp_labels[pass];
+    const int n = (int)lab.size();
+    std::vector<unsigned long long> t(n > 0 ? n : 1);
+    if (n > 0 && hipMemcpy(t.data(), rt->stamps + (size_t)pass * STAMP_CAP, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+      nunet_set_error("plan_calibrate: copy failed"); rc = NUNET_ELAUNCH; break;
+    }
+    rt->op_cost[pass].clear();
+    for (int k = 1; k < n; ++k) {
+      const size_t sp = lab[k].find(' ');                         // "L0 name"
+      if (sp == std::string::npos || t[k] <= t[k - 1]) continue;
+      // 100 MHz ticks; the stamp kernel and its node gap (~2 us) belong to the measurement, not to the op
+      const float us = (float)(t[k] - t[k - 1]) / 100.f - 2.f;
+      rt->op_cost[pass][lab[k].substr(sp + 1)] = us > 1.f ? us : 1.f;
+    }
+  }
+  static int keep = -1;
+  if (keep < 0) { const char* e = getenv("NUNET_STAMPS"); keep = e ? atoi(e) : 0; }
+  if (!keep) { (void)hipFree(rt->stamps); rt->stamps = nullptr; rt->stamp_labels[0].clear(); rt->stamp_labels[1].clear(); }
+  return rc;
+}
+
 extern "C" int nunet_debug_stamp(uint64_t* dst, nunet_stream_t s) {
   NUNET_REQUIRE(dst, "debug_stamp: null pointer");
   NUNET_LAUNCH(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, (unsigned long long*)dst);
@@ -1896,8 +2042,8 @@ extern "C" int nunet_plan_set_lanes(nunet_plan* P, nunet_stream_t* lanes, int32_
 }
 
 extern "C" int nunet_plan_set_schedule(nunet_plan* P, int32_t schedule) {
-  NUNET_REQUIRE(P && (schedule == NUNET_SCHEDULE_LANES || schedule == NUNET_SCHEDULE_WAVE), "plan_set_schedule: bad args");
-  rt_of(P)->wave = schedule == NUNET_SCHEDULE_WAVE ? 1 : 0;
+  NUNET_REQUIRE(P && (schedule == NUNET_SCHEDULE_LANES || schedule == NUNET_SCHEDULE_WAVE || schedule == NUNET_SCHEDULE_LIST), "plan_set_schedule: bad args");
+  rt_of(P)->wave = schedule;
   return NUNET_OK;
 }
 

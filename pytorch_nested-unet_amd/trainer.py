@@ -51,9 +51,9 @@ class TrainStep:
         x0 = torch.zeros(batch_shape, dtype=torch.float32, device=dev)
         self.pl = model.plan_for(x0)
         self.schedule = schedule or os.environ.get("NUNET_SCHEDULE", "lanes")
-        if self.schedule not in ("lanes", "wave"):
-            raise L.NunetError("TrainStep: schedule %r is not 'lanes' or 'wave'" % (self.schedule,))
-        L.check(L.lib().nunet_plan_set_schedule(self.pl.handle, 1 if self.schedule == "wave" else 0), "plan_set_schedule")
+        if self.schedule not in ("lanes", "wave", "list"):
+            raise L.NunetError("TrainStep: schedule %r is not 'lanes', 'wave' or 'list'" % (self.schedule,))
+        L.check(L.lib().nunet_plan_set_schedule(self.pl.handle, {"lanes": 0, "wave": 1, "list": 2}[self.schedule]), "plan_set_schedule")
         if segmented is None:
             segmented = {"0": False, "1": True, "2": "flags", "flags": "flags"}.get(os.environ.get("NUNET_SEGMENTED", "0"), False)
         self.segmented = segmented
@@ -340,6 +340,18 @@ class TrainStep:
             # dependencies as events between graph launches (csrc/graph.hip nunet_seg_*: explicit node -> queue placement on lanes
             # chosen by measurement; 2.33 vs 1.91 ms per step on MI355X: every segment launch costs 10-13 us on its lane)
             body = lambda: (self._fwd_bwd(), self._opt())
+            if self.schedule == "list":
+                # the list scheduler's per-op costs, measured: one step on ONE lane with a device timestamp behind every op
+                L.check(L.lib().nunet_plan_calibrate(self.pl.handle, 1), "plan_calibrate")
+                try:
+                    g = _NativeGraph(s, body)
+                    with torch.cuda.stream(s):
+                        for _ in range(3):
+                            g.replay()
+                    torch.cuda.synchronize()
+                finally:
+                    L.check(L.lib().nunet_plan_calibrate(self.pl.handle, 0), "plan_calibrate")
+                del g
             self.g_fb = _SegProgram(s, body, flags=self.segmented == "flags") if self.segmented else _NativeGraph(s, body)
         else:
             if self.dp_auto:

@@ -715,16 +715,16 @@ def test_segmented_step_program_equals_the_single_graph(synth):
     sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, True).state_dict().items()}
     batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=300 + k) for k in range(3)]
     outs = []
-    for seg in (False, True, "flags"):
+    for seg, sched in ((False, "lanes"), (True, "lanes"), ("flags", "lanes"), ("flags", "list"), (False, "list")):
         m = nunet_amd.archs.NestedUNet(1, 3, True, dtype="bf16")
         m.load_state_dict(sd)
         m = m.to(DEV).train()
-        ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, segmented=seg)
+        ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, segmented=seg, schedule=sched)
         ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
         assert isinstance(ts.g_fb, _SegProgram) == bool(seg)
         if seg:
             info = ts.g_fb.info()
-            print("segmented program (%s):" % seg, info)
+            print("segmented program (%s, %s):" % (seg, sched), info)
             assert info["event_waits"] >= info["event_records"] > 0 and info["kernel_nodes"] > 100
             # flag-synchronised lanes: ONE single-stream graph per lane; event mode: a graph per segment between two cuts
             assert (1 <= info["graph_launches"] <= 4) if seg == "flags" else info["graph_launches"] > 4
