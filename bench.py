@@ -344,6 +344,9 @@ def main():
             # what a SCALE record needs to be checkable: the ranks the collective backend really joined, the step layout the
             # data-parallel TrainStep chose and the timings it chose by (None with one rank: no exchange in the step)
             "dp": dp_info,
+            "executor": {"segmented": ts.segmented, "schedule": ts.schedule,
+                         "chosen_by": "timing at capture" if ts.executor_choice else "argument / environment / data-parallel default",
+                         "ms": {"%s/%s" % k: round(v, 4) for k, v in ts.executor_choice.items()} if ts.executor_choice else None},
         }
         print(json.dumps(out))
     if world > 1 or force_dp:

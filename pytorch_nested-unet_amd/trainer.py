@@ -38,10 +38,15 @@ class TrainStep:
         per-sample augmentation codes; Normalize, /255, the mask scaling, rot90 / flips and the layout change of the
         reference's sample pipeline (dataset.py:66-74, trains.py:258-266) run as the first two launches of the step's graph
         (step_u8). Only uint8 crosses PCIe and the per-step NCHW->NHWC launch of the float path is gone.
-        schedule: 'lanes' (default: the plan's forked streams, one multi-branch hipGraph) or 'wave' (one stream, list scheduler,
-        grouped convolution launches); segmented: record the lane schedule as a program of single-stream graph segments instead of
-        one graph. Both alternatives are bit-identical to the default and slower on ROCm 7.2; None reads
-        NUNET_SCHEDULE / NUNET_SEGMENTED (tools)."""
+        How the captured step is executed (all forms are bit-identical, tests/test_net_gpu.py):
+          schedule  'lanes' - every op on its block's lane; 'list' - lanes chosen by a list scheduler over the hazard graph with
+                    measured per-op costs (nunet_plan_calibrate); 'wave' - one stream, grouped convolution launches
+          segmented False - ONE hipGraph, the lanes as parallel branches (ROCm replays those node by node from the host);
+                    'flags' - one single-stream graph per lane, cross-lane dependencies as device-side flags (csrc/graph.hip);
+                    True - single-stream graph segments with events between graph launches
+        Both None (default): single-process training times (False, 'lanes') against ('flags', 'list') on the captured step and
+        keeps the faster (self.executor_choice); data-parallel training keeps (False, 'lanes'), whose graph can hold the RCCL
+        exchange. NUNET_SCHEDULE / NUNET_SEGMENTED force a form (tools)."""
         self.model = model
         self.eng = model.engine()
         dev = self.eng.device
@@ -50,13 +55,17 @@ class TrainStep:
         self.ncls = model.num_classes
         x0 = torch.zeros(batch_shape, dtype=torch.float32, device=dev)
         self.pl = model.plan_for(x0)
-        self.schedule = schedule or os.environ.get("NUNET_SCHEDULE", "lanes")
+        env_sched, env_seg = os.environ.get("NUNET_SCHEDULE"), os.environ.get("NUNET_SEGMENTED")
+        self.executor_auto = schedule is None and segmented is None and env_sched is None and env_seg is None
+        self.executor_choice = None          # {(segmented, schedule): ms per step} when the form was chosen by timing
+        self.schedule = schedule or env_sched or "lanes"
         if self.schedule not in ("lanes", "wave", "list"):
             raise L.NunetError("TrainStep: schedule %r is not 'lanes', 'wave' or 'list'" % (self.schedule,))
-        L.check(L.lib().nunet_plan_set_schedule(self.pl.handle, {"lanes": 0, "wave": 1, "list": 2}[self.schedule]), "plan_set_schedule")
+        self._set_schedule(self.schedule)
         if segmented is None:
-            segmented = {"0": False, "1": True, "2": "flags", "flags": "flags"}.get(os.environ.get("NUNET_SEGMENTED", "0"), False)
+            segmented = {"0": False, "1": True, "2": "flags", "flags": "flags"}.get(env_seg or "0", False)
         self.segmented = segmented
+        self._calibrated = False
         self.heads = self.pl.heads
         self.x = x0
         self.t = torch.zeros((n, self.ncls, h, w), dtype=torch.float32, device=dev)
@@ -340,19 +349,10 @@ class TrainStep:
             # dependencies as events between graph launches (csrc/graph.hip nunet_seg_*: explicit node -> queue placement on lanes
             # chosen by measurement; 2.33 vs 1.91 ms per step on MI355X: every segment launch costs 10-13 us on its lane)
             body = lambda: (self._fwd_bwd(), self._opt())
-            if self.schedule == "list":
-                # the list scheduler's per-op costs, measured: one step on ONE lane with a device timestamp behind every op
-                L.check(L.lib().nunet_plan_calibrate(self.pl.handle, 1), "plan_calibrate")
-                try:
-                    g = _NativeGraph(s, body)
-                    with torch.cuda.stream(s):
-                        for _ in range(3):
-                            g.replay()
-                    torch.cuda.synchronize()
-                finally:
-                    L.check(L.lib().nunet_plan_calibrate(self.pl.handle, 0), "plan_calibrate")
-                del g
-            self.g_fb = _SegProgram(s, body, flags=self.segmented == "flags") if self.segmented else _NativeGraph(s, body)
+            if self.executor_auto:
+                self._choose_executor(s, body)
+            else:
+                self.g_fb = self._build_executor(s, body, self.segmented, self.schedule)
         else:
             if self.dp_auto:
                 self._choose_layout(s)
@@ -379,6 +379,63 @@ class TrainStep:
                 dst.copy_(src)
         self.steps = steps0
         self.sync_weights()            # the restored parameters, repacked
+
+    def _set_schedule(self, schedule):
+        self.schedule = schedule
+        L.check(L.lib().nunet_plan_set_schedule(self.pl.handle, {"lanes": 0, "wave": 1, "list": 2}[schedule]), "plan_set_schedule")
+
+    def _build_executor(self, s, body, segmented, schedule):
+        """The step body recorded in one of its executable forms (see __init__)."""
+        self._set_schedule(schedule)
+        self.segmented = segmented
+        if schedule == "list" and not self._calibrated:
+            # the list scheduler's per-op costs, measured: the step on ONE lane with a device timestamp behind every op
+            L.check(L.lib().nunet_plan_calibrate(self.pl.handle, 1), "plan_calibrate")
+            try:
+                g = _NativeGraph(s, body)
+                with torch.cuda.stream(s):
+                    for _ in range(3):
+                        g.replay()
+                torch.cuda.synchronize()
+            finally:
+                L.check(L.lib().nunet_plan_calibrate(self.pl.handle, 0), "plan_calibrate")
+            del g
+            self._calibrated = True
+        return _SegProgram(s, body, flags=segmented == "flags") if segmented else _NativeGraph(s, body)
+
+    def _choose_executor(self, s, body, reps=20):
+        """Time the two executable forms of the captured step on this device and keep the faster: the multi-branch hipGraph
+        with block lanes, and the flag-synchronised single-stream graphs with list-scheduled lanes. (The caller restores the
+        training state.) A form that cannot be recorded or replayed here - e.g. no two streams on distinct hardware queues -
+        drops out with a message."""
+        forms = [(False, "lanes"), ("flags", "list")]
+        progs, times = {}, {}
+        for form in forms:
+            try:
+                g = self._build_executor(s, body, *form)
+                with torch.cuda.stream(s):
+                    for _ in range(3):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        g.replay()
+                    e1.record()
+                torch.cuda.synchronize()
+                g.replay()                       # (a cross-lane wait that timed out fails the NEXT launch)
+                torch.cuda.synchronize()
+                progs[form], times[form] = g, e0.elapsed_time(e1) / reps
+            except Exception as e:
+                if form == forms[0]:
+                    raise
+                print("[nunet] executor %s/%s is not available here: %s" % (form[0], form[1], e))
+        best = min(times, key=times.get)
+        self.executor_choice = times
+        self.g_fb = progs.pop(best)
+        progs.clear()
+        self._set_schedule(best[1])
+        self.segmented = best[0]
 
     def _capture_one_pass(self, s):
         """Layouts 1 and 2: forward + loss + the whole backward as one graph (layout 2: with the bucket-0 event recorded
