@@ -487,7 +487,8 @@ extern "C" int nunet_bn_relu_bwd_apply(const nunet_bn_bwd_desc* d, nunet_stream_
 // instead of a separate pass (nunet_bn_relu_bwd_reduce) that would read the gradient and the raw conv output again.
 // Used by the head backward (the last writer of x0_4's gradient, first kernel of the backward chain). The same fusion in
 // the upsample- and pool-backward kernels was measured and dropped: those run thousands of small latency-bound blocks,
-// and 2C fixed-point adds per block cost more (fused 21.9 us vs 9.4 + 8.6 us for the plain kernel + the fat-block reduce).
+// and 2C fixed-point adds per block cost more (fused 21.9 us vs 9.4 + 8.6 us for the plain kernel + the fat-block reduce;
+// round 3, again with at most 256 blocks and the list-scheduled executor: fused 17.6-25.9 us against 6.5-15.3 + 9.0-12.4).
 // A thread's channel group is fixed (the launch geometry keeps grid stride % G == 0): coefficients and the two partial
 // sums of its EPV channels live in registers; the block reduces them in a fixed order, then one fixed-point add each.
 // ---------------------------------------------------------------------------
