@@ -237,12 +237,14 @@ def main():
     if world > 1 or force_dp:
         dp_info = {"backend": dist.get_backend(), "rccl_ranks_seen": dist.get_world_size(), "layout": ts.dp_mode,
                    "layout_chosen_by": "measurement at capture (slowest rank decides)" if ts.dp_choice else "NUNET_DP_MODE / default",
-                   "layout_ms": {{1: "exchange_after_pass", 2: "bucket0_event_in_graph", 3: "exchange_inside_graph"}.get(k, str(k)): v
-                                 for k, v in ts.dp_choice.items()} if ts.dp_choice else None,
+                   "layout_ms": dict(ts.dp_choice) if ts.dp_choice else None,
                    "exchange_mb": ts._scratch.numel() * 4 / 1e6}
 
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt
+    executor = {"segmented": ts.segmented, "schedule": ts.schedule,
+                "chosen_by": "timing at capture" if ts.executor_choice else "argument / environment / data-parallel default",
+                "ms": {"%s/%s" % k: round(v, 4) for k, v in ts.executor_choice.items()} if ts.executor_choice else None}
 
     roofline = None
     if not args.no_roofline and rank == 0 and world == 1:     # single-process leg: no collectives inside
@@ -315,11 +317,12 @@ def main():
         del ts
         torch.cuda.empty_cache()
         k32 = max(20, args.fp32_steps)
-        _, dt32 = timed_run("fp32", k32, 5)
+        ts32, dt32 = timed_run("fp32", k32, 5)
         ms32 = dt32 / k32 * 1e3
         tf32 = train_gflop_per_img(hw) * n / 1e3 / (ms32 * 1e-3)
         fp32 = {"value": n * k32 / dt32, "unit": "images/sec", "ms_per_step": ms32, "steps": k32, "warmup": 5,
                 "whole_step_tflops": tf32, "frac_of_fp32_mfma_peak": tf32 / PEAK["fp32"],
+                "executor": "%s/%s" % (ts32.segmented, ts32.schedule),
                 "note": "same workload and step, fp32 storage and exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference's precision"}
 
     cpu = None
@@ -344,9 +347,9 @@ def main():
             # what a SCALE record needs to be checkable: the ranks the collective backend really joined, the step layout the
             # data-parallel TrainStep chose and the timings it chose by (None with one rank: no exchange in the step)
             "dp": dp_info,
-            "executor": {"segmented": ts.segmented, "schedule": ts.schedule,
-                         "chosen_by": "timing at capture" if ts.executor_choice else "argument / environment / data-parallel default",
-                         "ms": {"%s/%s" % k: round(v, 4) for k, v in ts.executor_choice.items()} if ts.executor_choice else None},
+            # how the captured step is executed (TrainStep picks between the multi-branch hipGraph and the flag-synchronised
+            # list-scheduled lanes by timing both at capture)
+            "executor": executor,
         }
         print(json.dumps(out))
     if world > 1 or force_dp:

@@ -978,7 +978,8 @@ static void seg_pick_lanes(PlanRt* rt, hipStream_t main_s) {
   hipStream_t pick[3]; int np = 0;
   bool usedc[NC] = {false};
   for (int k = 0; k < nc && np < 3; ++k) {
-    bool ok = overlap(main_s, cand[k]);
+    // (also clear of the process's default stream: the copies of the next batch are usually queued there)
+    bool ok = overlap(main_s, cand[k]) && overlap((hipStream_t)nullptr, cand[k]);
     for (int q = 0; q < np && ok; ++q) ok = overlap(pick[q], cand[k]);
     if (ok) { pick[np++] = cand[k]; usedc[k] = true; }
   }
