@@ -676,6 +676,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvGroup grp)
       s_bnc[c] = mean; s_bnc[p.Cout + c] = istd; s_bnc[2 * p.Cout + c] = sc; s_bnc[3 * p.Cout + c] = __builtin_fmaf(-mean, sc, p.bn_beta[c]);
     }
   }
+  // (measured and not kept, round 3: requesting those sums at the very top of the kernel - into registers, 64 VGPRs and a
+  //  workgroup less per CU, or as a one-dword-per-line touch - so that their round trip runs under the index-table prologue:
+  //  the lines were last written by the producer's memory-side atomics and come back slowly, the vector-memory counter is
+  //  in order, and the first tile's staging loads - issued later - then wait behind them: +1.7 % over the 59 conv launches)
   if constexpr (LT == 1) {
     // BatchNorm coefficients of the INPUT channels, from the producing conv's fixed-point sums (every workgroup
     // derives the same values; workgroup 0 also owns the running-statistics update and the saved mean / invstd)
