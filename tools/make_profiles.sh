@@ -9,6 +9,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$OUT
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# the executor is pinned to the single hipGraph: the capture-time choice would otherwise run its trial steps under the profiler
+# (extra launches in the per-step counts), and the flag-synchronised lanes' polling kernels spin for as long as the profiler
+# serialises the queues (9.6 ms per step under --kernel-trace). Kernel durations do not depend on the executor.
+export NUNET_SEGMENTED=0 NUNET_SCHEDULE=lanes
 W="--size $SIZE --batch $BATCH --no-cpu-baseline --no-roofline --no-fp32"
 B="$R/bench.py --steps 20 --warmup 5 $W"
 keep() {  # keep() <dir> <pattern> <dest>: copy the one csv we need, drop the rest
