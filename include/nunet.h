@@ -380,6 +380,13 @@ int nunet_plan_bucket0_wait(nunet_plan* p, nunet_stream_t s);
  * receives the scaled gradients. */
 int nunet_plan_update(nunet_plan* p, float* params, float* momentum, void* arena, size_t arena_bytes, const float* lr_dev, float mom, float wd,
                       int32_t nesterov, float grad_scale, float* grads, nunet_stream_t s);
+/* The optimiser step INSIDE the backward pass: once parameters are set here, every whole backward pass steps each VGGBlock's
+ * parameters (scratch -> SGD -> both packed 16-bit layouts, the arithmetic of nunet_plan_update) as an op scheduled behind that
+ * block's weight gradients, beside the rest of the pass, and the heads at its end. The caller then calls neither
+ * nunet_plan_update nor nunet_plan_sgd and sets bit 1 of the next forward's training flags (weights current).
+ * Single-process training only (a data-parallel step exchanges the gradients before the update). params = NULL: off. */
+int nunet_plan_set_inpass_update(nunet_plan* p, float* params, float* momentum, const float* lr_dev, float mom, float wd,
+                                 int32_t nesterov, float grad_scale, float* grads);
 /* The same optimiser step without the repack (the next nunet_plan_forward repacks as usual): gradient scratch -> SGD,
  * one launch instead of unpack + nunet_sgd_step, no OIHW gradient round trip unless `grads` is given. */
 int nunet_plan_sgd(nunet_plan* p, float* params, float* momentum, void* arena, size_t arena_bytes, const float* lr_dev, float mom, float wd,

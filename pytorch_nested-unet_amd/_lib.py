@@ -153,6 +153,7 @@ _SIG = {
     "nunet_plan_bucket0_enable": (_i32, [_vp, _i32]),
     "nunet_plan_bucket0_wait": (_i32, [_vp, _vp]),
     "nunet_plan_update": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
+    "nunet_plan_set_inpass_update": (_i32, [_vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32, _vp]),
     "nunet_plan_repack": (_i32, [_vp, _vp, _vp, _sz, _vp]),
     "nunet_plan_sgd": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp, _f32, _f32, _i32, _f32, _vp, _vp]),
     "nunet_plan_feature": (_i64, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void unpack_tiled_kernel(const float* __restri
 // also steps the layer's conv bias and BatchNorm gamma / beta; blocks past the last tile own the 1x1 heads
 // (sum of their gradient slabs, then the same step). torch.optim.SGD semantics (reference trains.py:229-231).
 // ---------------------------------------------------------------------------------------------------------
-struct UpdP { float* params; float* mom; const float* scratch; float* grads; const float* lr; float momc, wd, gscale; int nesterov; int nconv; };
+struct UpdP { float* params; float* mom; const float* scratch; float* grads; const float* lr; float momc, wd, gscale; int nesterov; int nconv;
+              int bid_off; };   // first block's index in the whole-model block numbering (a launch may cover one VGGBlock's tiles, or the heads)
 
 __device__ __forceinline__ float sgd_one(float p, float g, float* m, const UpdP& u, float lr) {
   float gv = g + u.wd * p;
@@ -279,9 +280,10 @@ __global__ __launch_bounds__(512) void update_kernel(UpdP u, T* __restrict__ are
   __shared__ float s_t[32][32 * 9 + 1];
   __shared__ float s_g[32][32 * 9 + 1];
   const float lr = u.lr[0];
-  if ((int)blockIdx.x >= tab.ntiles) {
+  const int bid = (int)blockIdx.x + u.bid_off;
+  if (bid >= tab.ntiles) {
     // ---- 1x1 head: sum the gradient slabs (fixed order), then the step; <= 264 elements
-    const UnpackEnt en = ut.e[u.nconv + (int)blockIdx.x - tab.ntiles];
+    const UnpackEnt en = ut.e[u.nconv + bid - tab.ntiles];
     const float* dw = u.scratch + en.src;
     const int tot = en.cout * en.cin * en.taps + en.nvec * en.cout;
     const int B = blockDim.x;     // B/ne threads share an element's slabs (see unpack_sgd_tiled_kernel), fixed order
@@ -311,10 +313,10 @@ __global__ __launch_bounds__(512) void update_kernel(UpdP u, T* __restrict__ are
     return;
   }
   int e = 0;
-  while (e + 1 < tab.n && (int)blockIdx.x >= tab.tile0[e + 1]) ++e;
+  while (e + 1 < tab.n && bid >= tab.tile0[e + 1]) ++e;
   const PackEnt en = tab.e[e];
   const UnpackEnt ue = ut.e[e];
-  const int t = blockIdx.x - tab.tile0[e];
+  const int t = bid - tab.tile0[e];
   const int nci = (en.cinpad + 31) / 32;
   const int co0 = (t / nci) * 32, ci0 = (t % nci) * 32;
   const float* w = u.params + en.src;
@@ -458,6 +460,8 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   // NUNET_STAMPS=1 diagnostic: a 1-thread kernel after every scheduled op writes the 100 MHz wall clock,
   // so the real timeline of an (unprofiled) hipGraph replay can be read back (tools/stamp_timeline.py)
   unsigned long long* stamps;              // device, [2][STAMP_CAP]
+  // nunet_plan_set_inpass_update: the optimiser step of every VGGBlock as an op of the backward pass (params == NULL: off)
+  struct { float* params; float* mom; const float* lr; float momc, wd, gscale; int nesterov; float* grads; } upd;
   int calibrating;                         // nunet_plan_calibrate: single lane + stamps, to measure every op's isolated cost
   std::map<std::string, float> op_cost[2]; // measured cost (us) by op name, per pass; empty: the built-in estimates
   hipEvent_t b0_event;                     // recorded when the first gradient bucket (phase-1 nodes + heads) is complete
@@ -697,6 +701,8 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->cap_next = 0;
   rt->stamps = nullptr;
   rt->calibrating = 0;
+  memset(&rt->upd, 0, sizeof(rt->upd));
+  { PackTab& tab = P->ptab; int nt = 0; for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); } tab.tile0[tab.n] = nt; tab.ntiles = nt; }
   rt->b0_event = nullptr; rt->b0_enabled = false; rt->open_sched = nullptr;
   rt->seg_lanes[0] = rt->seg_lanes[1] = rt->seg_lanes[2] = nullptr;
   rt->events_used[0] = rt->events_used[1] = 0;
@@ -766,8 +772,8 @@ static inline char* AB(void* arena, size_t off) { return (char*)arena + off; }
 // per-buffer tracker (last-writer event, last-reader event per lane). Captured by the
 // caller, the lanes become parallel branches of ONE hipGraph.
 // ---------------------------------------------------------------------------
-#define NRES 496
-enum { R_X = 0, R_GX = 25, R_BLK = 50, R_LVL = 330, R_IMG = 230, R_LOGITS = 231, R_DLOGITS = 232, R_WP = 233, R_GS = 238, R_SK = 470, R_GSW = 240, R_GSV = 280 };
+#define NRES 512
+enum { R_X = 0, R_GX = 25, R_BLK = 50, R_LVL = 330, R_IMG = 230, R_LOGITS = 231, R_DLOGITS = 232, R_WP = 233, R_GS = 238, R_SK = 470, R_GSW = 240, R_GSV = 280, R_PRM = 485 };
 enum { B_Y1 = 0, B_A1, B_Y2, B_UP, B_PIN, B_ST1, B_ST2, B_STRIDE = 8 };
 enum { L_DY0 = 0, L_DY1, L_DA1, L_GUP, L_GPIN, L_STRIDE = 8 };
 
@@ -1466,7 +1472,7 @@ extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, 
   tab.tile0[tab.n] = nt; tab.ntiles = nt;
   UpdP u;
   u.params = params; u.mom = momentum; u.scratch = (const float*)AB(arena, P->off_gs); u.grads = grads; u.lr = lr_dev;
-  u.momc = mom; u.wd = wd; u.gscale = grad_scale; u.nesterov = nesterov; u.nconv = tab.n;
+  u.momc = mom; u.wd = wd; u.gscale = grad_scale; u.nesterov = nesterov; u.nconv = tab.n; u.bid_off = 0;
   const int nheads = P->utab.n - tab.n;
   ProfScope ps(PC_SGD, 0, (double)P->nparams * (grads ? 28.0 : 24.0), st);
   void* wp = AB(arena, P->off_wpack);
@@ -1475,6 +1481,34 @@ extern "C" int nunet_plan_update(nunet_plan* P, float* params, float* momentum, 
   else if (P->cfg.dtype == NUNET_BF16) NUNET_LAUNCH((update_kernel<bf16_t>), grid, blk, 0, st, u, (bf16_t*)wp, tab, P->utab);
   else NUNET_LAUNCH((update_kernel<f16_t>), grid, blk, 0, st, u, (f16_t*)wp, tab, P->utab);
   return nunet_check_launch("plan_update");
+}
+
+// A slice of the same launch: blocks [bid0, bid0 + nblocks) of the whole-model numbering (one VGGBlock's tiles, or the heads)
+template <typename U> static int launch_update(nunet_plan* P, void* arena, const U& s, int bid0, int nblocks, hipStream_t st) {
+  if (nblocks <= 0) return NUNET_OK;
+  UpdP u;
+  u.params = s.params; u.mom = s.mom; u.scratch = (const float*)AB(arena, P->off_gs); u.grads = s.grads; u.lr = s.lr;
+  u.momc = s.momc; u.wd = s.wd; u.gscale = s.gscale; u.nesterov = s.nesterov; u.nconv = P->ptab.n; u.bid_off = bid0;
+  void* wp = AB(arena, P->off_wpack);
+  const dim3 grid(nblocks), blk(512);
+  ProfScope ps(PC_SGD, 0, 0.0, st);
+  if (P->cfg.dtype == NUNET_F32) NUNET_LAUNCH((update_kernel<float>), grid, blk, 0, st, u, (float*)wp, P->ptab, P->utab);
+  else if (P->cfg.dtype == NUNET_BF16) NUNET_LAUNCH((update_kernel<bf16_t>), grid, blk, 0, st, u, (bf16_t*)wp, P->ptab, P->utab);
+  else NUNET_LAUNCH((update_kernel<f16_t>), grid, blk, 0, st, u, (f16_t*)wp, P->ptab, P->utab);
+  return nunet_check_launch("plan update (in pass)");
+}
+
+// The optimiser step as part of the backward pass: with parameters set here, every whole pass (nunet_plan_backward, or
+// nunet_plan_backward_phase with bits 0 and 1) steps each VGGBlock's parameters - and repacks its 16-bit weights - as an op of
+// the pass, scheduled behind that block's weight gradients, and the heads at the end. The caller then calls neither
+// nunet_plan_update / nunet_plan_sgd nor lets the next forward repack (training flag bit 1). Single-process training only: a
+// data-parallel step exchanges the gradients first. params == NULL switches it off.
+extern "C" int nunet_plan_set_inpass_update(nunet_plan* P, float* params, float* momentum, const float* lr_dev, float mom, float wd,
+                                            int32_t nesterov, float grad_scale, float* grads) {
+  NUNET_REQUIRE(P && (!params || (momentum && lr_dev)), "plan_set_inpass_update: null pointer");
+  auto& s = rt_of(P)->upd;
+  s.params = params; s.mom = momentum; s.lr = lr_dev; s.momc = mom; s.wd = wd; s.gscale = grad_scale; s.nesterov = nesterov; s.grads = grads;
+  return NUNET_OK;
 }
 
 // Optimiser step straight from the gradient scratch: replaces nunet_plan_backward_phase bit 2 +
@@ -1578,7 +1612,7 @@ extern "C" int nunet_plan_sgd(nunet_plan* P, float* params, float* momentum, voi
   hipStream_t st = (hipStream_t)s;
   UpdP u;
   u.params = params; u.mom = momentum; u.scratch = (const float*)AB(arena, P->off_gs); u.grads = grads; u.lr = lr_dev;
-  u.momc = mom; u.wd = wd; u.gscale = grad_scale; u.nesterov = nesterov; u.nconv = P->ptab.n;
+  u.momc = mom; u.wd = wd; u.gscale = grad_scale; u.nesterov = nesterov; u.nconv = P->ptab.n; u.bid_off = 0;
   ProfScope ps(PC_SGD, 0, (double)P->nparams * (grads ? 24.0 : 20.0), st);
   PackTab& tab = P->ptab;
   int nt = 0;
@@ -1739,6 +1773,9 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
     written[0][h.slot] = true;
   }
   const bool b0_inside = (phases & 3) == 3 && rt_of(P)->b0_enabled && !P->cfg.unet;   // bucket 0 signalled from inside the pass
+  // in-pass optimiser step: only a WHOLE pass may carry it (a data-parallel caller exchanges the gradients between the phases)
+  const auto upd = rt_of(P)->upd;
+  const bool inpass = upd.params != nullptr && (phases & 3) == 3;
   // NUNET_DEBUG_SPIN_US (tests only): a spin kernel of that many microseconds heads phase 2 on the chain lane, so that
   // "bucket 0 is complete well before the pass ends" can be asserted with a margin (tests/test_dist_gpu.py)
   static int spin_us = -1;
@@ -1886,6 +1923,22 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
               return r ? r : launch_reduce(P, arena, k, k, ls);
             });
     }
+    // ---- in-pass optimiser step (nunet_plan_set_inpass_update): this block's two convolutions are stepped - scratch -> SGD ->
+    // both packed 16-bit layouts - as soon as their gradients are complete, beside the rest of the backward pass, instead of in
+    // one launch over all layers after it (43 us) plus the next forward's repack (15 us), with nothing to overlap either
+    if (inpass) {
+      int r0 = -1;
+      for (size_t r = 0; r < P->reg.size(); ++r) if (P->reg[r] == k) r0 = (int)r;
+      if (r0 >= 0) {
+        const PackTab& tab = P->ptab;
+        const int t0 = tab.tile0[2 * r0], t1 = tab.tile0[2 * r0 + 2];
+        const long long np = 9LL * (L1.cout * L1.cinpad + L2.cout * L2.cinpad);
+        S.name("B%d%d.upd", n.i, n.j);
+        S.add(wlane, 1, 4.f + (float)(np * 28.0 / 3.0e6), {R_GSW + 2 * k, R_GSW + 2 * k + 1, R_GSV + 2 * k, R_GSV + 2 * k + 1}, {R_PRM + k}, [=](hipStream_t ls) {
+          return launch_update(P, arena, upd, t0, t1 - t0, ls);
+        });
+      }
+    }
     // "bucket 0 complete" (data-parallel exchange beside the rest of the backward pass, nunet_plan_bucket0_*): on the otherwise
     // unused lane 4, ops that read every gradient resource of the phase-1 nodes and the heads; the last one sums the phase's
     // weight-gradient slabs and records the plan's event - as an external event record node when the pass is being captured
@@ -1908,6 +1961,14 @@ extern "C" int nunet_plan_backward_phase(nunet_plan* P, const float* params, con
         });
       }
     }
+  }
+  if (inpass && (phases & 1) && !P->heads.empty()) {
+    // the 1x1 heads: blocks past the last tile of the update kernel's numbering
+    int rs[12]; int nr = 0;
+    for (size_t h = 0; h < P->heads.size() && nr < 12; ++h) rs[nr++] = R_GSV + 30 + (int)h;
+    const int nh = P->utab.n - P->ptab.n, nt = P->ptab.ntiles;
+    S.name("heads.upd");
+    S.add_v(0, 1, 5.f, rs, nr, [=](hipStream_t ls) { return launch_update(P, arena, upd, nt, nh, ls); });
   }
   if (rc == NUNET_OK) rc = S.run();
   if (leave_open && rc == NUNET_OK && !S.failed) {

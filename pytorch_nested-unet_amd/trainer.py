@@ -127,8 +127,14 @@ class TrainStep:
         # also repacks the weights (nunet_plan_update). The flat OIHW gradients (p.grad views) are materialised with
         # keep_grads=True in the fused layouts; in every layout they hold the rank-MEAN gradient (as
         # DistributedDataParallel leaves p.grad).
+        # 3 = the optimiser step INSIDE the backward pass (nunet_plan_set_inpass_update): every VGGBlock is stepped and repacked
+        # as an op of the pass behind its weight gradients, beside the rest of the pass; single-process training only (a
+        # data-parallel step exchanges the gradients before the update: it falls back to 2).
         self.fused_update = int(os.environ.get("NUNET_FUSED_UPDATE", "2")) if fused_update is None else int(fused_update)   
+        if self.fused_update == 3 and self.dp:
+            self.fused_update = 2
         self.keep_grads = keep_grads
+        self._inpass_set = False
         self._packed = False          # the arena's packed weights match the fp32 parameters
         self.g_fb = None
         self.g_b2 = None
@@ -171,7 +177,7 @@ class TrainStep:
     def _fwd_loss(self):
         lib, eng, pl = L.lib(), self.eng, self.pl
         st = L.stream()
-        flags = 3 if (self.fused_update == 1 and self._packed) else 1
+        flags = 3 if (self.fused_update in (1, 3) and self._packed) else 1
         if self.input_u8:
             # the sample pipeline on the device: image -> the plan's padded NHWC tile, mask -> {0,1} fp32 NCHW target
             L.check(lib.nunet_plan_stage_u8(pl.handle, L.ptr(self.x_u8), L.ptr(self._mean), L.ptr(self._std), L.ptr(self.aug), 1.0 / 255.0,
@@ -197,6 +203,8 @@ class TrainStep:
     def _update(self):
         """scratch -> SGD -> repacked weights in one launch (replaces unpack + sgd + the next forward's repack)."""
         eng, pl = self.eng, self.pl
+        if self.fused_update == 3:      # already done, block by block, inside the backward pass
+            return
         if self.fused_update == 2:      # gradient scratch -> SGD in one launch; the next forward repacks
             L.check(L.lib().nunet_plan_sgd(pl.handle, L.ptr(eng.flat_params), L.ptr(self.mom), L.ptr(pl.arena), L.nbytes(pl.arena), L.ptr(self.lr),
                                            self.momentum, self.wd, 1 if self.nesterov else 0, 1.0 / self.world,
@@ -209,9 +217,24 @@ class TrainStep:
     def sync_weights(self):
         """Repack the plan's 16-bit weights from the fp32 parameters: call after changing the parameters by anything
         other than step() (load_state_dict, a stock optimiser) when fused_update is on."""
-        if self.fused_update == 1:
+        self._arm_inpass_update()
+        if self.fused_update in (1, 3):
             L.check(L.lib().nunet_plan_repack(self.pl.handle, L.ptr(self.eng.flat_params), L.ptr(self.pl.arena), L.nbytes(self.pl.arena), L.stream()), "plan_repack")
             self._packed = True
+
+    def _arm_inpass_update(self):
+        """fused_update 3: hand the plan the optimiser's state so that its backward pass carries the step (off otherwise)."""
+        on = self.fused_update == 3
+        if on == self._inpass_set:
+            return
+        eng = self.eng
+        if on:
+            L.check(L.lib().nunet_plan_set_inpass_update(self.pl.handle, L.ptr(eng.flat_params), L.ptr(self.mom), L.ptr(self.lr), self.momentum,
+                                                         self.wd, 1 if self.nesterov else 0, 1.0 / self.world,
+                                                         L.ptr(eng.flat_grads) if self.keep_grads else None), "plan_set_inpass_update")
+        else:
+            L.check(L.lib().nunet_plan_set_inpass_update(self.pl.handle, None, None, None, 0.0, 0.0, 0, 1.0, None), "plan_set_inpass_update")
+        self._inpass_set = on
 
     def _opt(self):
         if self.fused_update:
@@ -557,7 +580,7 @@ class TrainStep:
             else:
                 self.g_fb.replay()
         else:
-            if self.fused_update == 1 and not self._packed:
+            if self.fused_update in (1, 3) and not self._packed:
                 self.sync_weights()
             self._eager_step()
         self.steps += 1

@@ -557,6 +557,34 @@ def test_fused_update_equals_unpack_sgd_pack(dtype, mode, synth):
         assert torch.equal(l1, ts.logits)          # same packed weights, deterministic reductions: bit-identical
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("ds", [False, True])
+def test_optimiser_step_inside_the_backward_pass(dtype, ds, synth):
+    """fused_update=3 (nunet_plan_set_inpass_update): every VGGBlock - and the heads - stepped and repacked as an op of the backward
+    pass, behind its weight gradients. It is the arithmetic of nunet_plan_update (mode 1), launched in slices: after three captured
+    steps parameters, momentum, p.grad, BatchNorm buffers and losses are BIT-identical to mode 1's, under every executor."""
+    from nunet_amd.trainer import TrainStep
+    n, hw = 16, 96
+    torch.manual_seed(21)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, ds).state_dict().items()}
+    batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=500 + k) for k in range(3)]
+    outs = []
+    for mode, seg, sched in ((1, False, "lanes"), (3, False, "lanes"), (3, "flags", "list")):
+        m = nunet_amd.archs.NestedUNet(1, 3, ds, dtype=dtype)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, momentum=0.9, weight_decay=1e-4, nesterov=True, fused_update=mode, segmented=seg, schedule=sched)
+        ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+        for img, msk in batches:
+            ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (ts.eng.flat_params, ts.mom, ts.eng.flat_grads, ts.eng.bnbuf, ts.loss_out)])
+        del ts, m
+    for other in outs[1:]:
+        for a, b, nm in zip(outs[0], other, ("params", "momentum", "grads", "bn buffers", "loss")):
+            assert torch.equal(a, b), nm
+
+
 @pytest.mark.parametrize("ds", [False, True])
 @pytest.mark.parametrize("graph", [False, True])
 def test_lovasz_hinge_inside_the_fused_step(ds, graph, synth):
