@@ -232,7 +232,7 @@ thread_local bool g_dry_run = false;
 // ---------------------------------------------------------------------------------------------------------
 constexpr unsigned long long LANE_WAIT_TIMEOUT_TICKS = 400000000ull;   // s_memrealtime runs at 100 MHz: 4 s
 constexpr int LANE_SYNC_MAX = 12;          // signals / waits per sync kernel (more: a second kernel)
-struct LaneSyncP { unsigned* flags; unsigned* ctr; unsigned* err; int bump, nsig, nwait; unsigned short sig[LANE_SYNC_MAX], wait[LANE_SYNC_MAX]; };
+struct LaneSyncP { unsigned* flags; unsigned* ctr; unsigned* err; unsigned* derr; int bump, nsig, nwait; unsigned short sig[LANE_SYNC_MAX], wait[LANE_SYNC_MAX]; };
 __global__ __launch_bounds__(64) void lane_sync_kernel(LaneSyncP p) {
   __shared__ unsigned s_step;
   const int t = threadIdx.x;
@@ -243,9 +243,13 @@ __global__ __launch_bounds__(64) void lane_sync_kernel(LaneSyncP p) {
   if (t >= 32 && t - 32 < p.nwait) {
     const unsigned* flag = p.flags + p.wait[t - 32];
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    // (once one wait of the program has timed out, every later one gives up at its first poll: a broken schedule costs ONE
+    //  timeout, not one per sync kernel; the device-side copy of the error word keeps that check off the PCIe bus)
+    unsigned long long limit = __hip_atomic_load(p.derr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0ull : LANE_WAIT_TIMEOUT_TICKS;
     while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) < 0) {
       __builtin_amdgcn_s_sleep(4);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > LANE_WAIT_TIMEOUT_TICKS) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
+        __hip_atomic_store(p.derr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p.err, (unsigned)p.wait[t - 32] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
@@ -289,7 +293,7 @@ struct SegRec {
       begin_capture(st);
       if (failed) return;
       LaneSyncP a; memset(&a, 0, sizeof(a));
-      a.flags = dflags; a.ctr = ctr_of(st); a.err = herr; a.bump = p.bumped ? 0 : 1; p.bumped = true;
+      a.flags = dflags; a.ctr = ctr_of(st); a.err = herr; a.derr = dflags + MAXF + MAXL; a.bump = p.bumped ? 0 : 1; p.bumped = true;
       while (a.nsig < LANE_SYNC_MAX && !p.sig.empty()) { a.sig[a.nsig++] = (unsigned short)p.sig.front(); p.sig.erase(p.sig.begin()); }
       // (waits go out only with the LAST signals: a wait must not precede a record that was made before it)
       if (p.sig.empty()) while (a.nwait < LANE_SYNC_MAX && !p.wait.empty()) { a.wait[a.nwait++] = (unsigned short)p.wait.front(); p.wait.erase(p.wait.begin()); }
@@ -411,7 +415,7 @@ extern "C" int nunet_seg_begin(nunet_stream_t s, int32_t mode) {
   r->dry = mode == NUNET_SEG_DRY; r->main = (hipStream_t)s;
   if (mode == NUNET_SEG_FLAGS) {
     r->flags_mode = true;
-    const size_t bytes = sizeof(unsigned) * (SegRec::MAXF + SegRec::MAXL);
+    const size_t bytes = sizeof(unsigned) * (SegRec::MAXF + SegRec::MAXL + 1);      // flags | lane counters | device copy of the error word
     if (hipMalloc((void**)&r->dflags, bytes) != hipSuccess || hipMemset(r->dflags, 0, bytes) != hipSuccess ||
         hipHostMalloc((void**)&r->herr, sizeof(unsigned), hipHostMallocDefault) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       nunet_set_error("seg_begin: cannot allocate the lane flags: %s", hipGetErrorString(hipGetLastError()));
