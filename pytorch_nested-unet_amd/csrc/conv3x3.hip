@@ -1028,6 +1028,12 @@ static int launch_conv_cfg(const nunet_conv_desc* const* ds, int n, hipStream_t 
 //  the weight stage shared by 4.5 x the pixels, every B fragment feeding three MFMAs - is 10-30 % SLOWER on every level-0 layer:
 //  six waves land 2-2-1-1 on the four SIMDs, the nine staging units per thread push the kernel to 256 registers with spills, and
 //  one workgroup per CU loses what co-resident workgroups still overlap; capping today's kernel at one workgroup per CU costs 20 %.)
+// (round 3, measured and not kept: a double-buffered LDS loop for the 128 x 32 tile - the next chunk's staging (wait, transform,
+//  16-byte LDS writes) and the loads of the chunk after it spread over the MFMA steps of the current sweep, ONE barrier per chunk,
+//  2 x 38 KB - is bit-correct and 8.5 % SLOWER over the 59 launches (level-0 conv1 +17 %, level-2 conv2 +40 %): a chunk's time is
+//  set by the latency of its 12 staging loads per thread against the bytes a CU has in flight (2-3 workgroups x 30 KB per ~2 us),
+//  not by the write / barrier / sweep phases being serial; the second image halves the resident workgroups and buys no distance -
+//  a load still has one sweep to arrive. What would: 3-4 chunk images landed by LDS-DMA loads, i.e. no staging registers at all.)
 // 0: 128 x 32, 1: 128 x 64, 2: 256 x 32
 static int conv_cfg_of(const nunet_conv_desc* d) {
   const int cout = d->D0 + d->D1;
