@@ -1033,7 +1033,16 @@ static int launch_conv_cfg(const nunet_conv_desc* const* ds, int n, hipStream_t 
 //  2 x 38 KB - is bit-correct and 8.5 % SLOWER over the 59 launches (level-0 conv1 +17 %, level-2 conv2 +40 %): a chunk's time is
 //  set by the latency of its 12 staging loads per thread against the bytes a CU has in flight (2-3 workgroups x 30 KB per ~2 us),
 //  not by the write / barrier / sweep phases being serial; the second image halves the resident workgroups and buys no distance -
-//  a load still has one sweep to arrive. What would: 3-4 chunk images landed by LDS-DMA loads, i.e. no staging registers at all.)
+//  a load still has one sweep to arrive. Then built as well: an LDS-DMA loader for the plain 16-bit 128 x 32 convs - three or four
+//  lane-linear 32 KB chunk images (64-byte rows, the bank swizzle on the SOURCE address: slot s of row r fetches channel segment
+//  s ^ ((r >> 2) & 3), the fragment reads XOR the same), `global_load_lds_dwordx4` through inline asm (hipcc puts an s_waitcnt
+//  vmcnt(0) in front of the first fragment read after every LDS-DMA it knows of), a counted vmcnt(8 / 16) and ONE raw s_barrier per
+//  chunk, no staging registers, one workgroup per CU. Bit-correct (118 op tests) and 39 % SLOWER over the 15 first convs of the
+//  blocks (314 -> 436 us), identically with 3 and with 4 images: not latency either. With one wave per SIMD nothing overlaps the
+//  wave's own instruction stream - address generation of the 8 DMA instructions (~0.4 us), the sweep's 18 dependent MFMAs (~0.5 us),
+//  the epilogue (2.5 us per item) run one after the other -, whereas the register-staged kernel's 2-3 co-resident workgroups fill
+//  each other's gaps: 1.2 us per chunk and CU against 1.5-1.9. What this kernel needs is the staging work INSIDE the MFMA gaps of
+//  the same wave and two accumulator chains per wave, not more loads in flight.)
 // 0: 128 x 32, 1: 128 x 64, 2: 256 x 32
 static int conv_cfg_of(const nunet_conv_desc* d) {
   const int cout = d->D0 + d->D1;
