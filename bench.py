@@ -243,7 +243,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt
     executor = {"segmented": ts.segmented, "schedule": ts.schedule,
-                "chosen_by": "timing at capture" if ts.executor_choice else "argument / environment / data-parallel default",
+                "chosen_by": "timing at capture" if ts.executor_choice else ("data-parallel layout timing (dp.layout_ms)" if ts.dp_choice else "argument / environment"),
                 "ms": {"%s/%s" % k: round(v, 4) for k, v in ts.executor_choice.items()} if ts.executor_choice else None}
 
     roofline = None

@@ -409,6 +409,10 @@ int nunet_plan_set_multistream(nunet_plan* p, int32_t enable);
  * nunet_plan_calibrate(p, 0) replaces the built-in cost estimates by the measured isolated cost of every op. */
 enum { NUNET_SCHEDULE_LANES = 0, NUNET_SCHEDULE_WAVE = 1, NUNET_SCHEDULE_LIST = 2 };
 int nunet_plan_calibrate(nunet_plan* p, int32_t begin);
+/* Side lanes of the flag-synchronised program at the lowest stream priority (default 1: the chain lane's workgroups are dispatched
+ * first) or at the default priority (0: needed when another library's high-priority stream lives in the process - RCCL's -,
+ * beside which lowest-priority queues are served in time slices). Set before the first recording. */
+int nunet_plan_set_lane_priority(nunet_plan* p, int32_t lowest);
 int nunet_plan_set_schedule(nunet_plan* p, int32_t schedule);
 /* debug/test access to an intermediate: name like "x0_0", "x2_1" (block
  * outputs, NHWC). Returns byte offset into arena; fills pitch/channels. */

@@ -462,6 +462,7 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   unsigned long long* stamps;              // device, [2][STAMP_CAP]
   // nunet_plan_set_inpass_update: the optimiser step of every VGGBlock as an op of the backward pass (params == NULL: off)
   struct { float* params; float* mom; const float* lr; float momc, wd, gscale; int nesterov; float* grads; } upd;
+  int lane_low_priority;                   // side lanes of the flag-synchronised program at the lowest stream priority (default 1)
   int calibrating;                         // nunet_plan_calibrate: single lane + stamps, to measure every op's isolated cost
   std::map<std::string, float> op_cost[2]; // measured cost (us) by op name, per pass; empty: the built-in estimates
   hipEvent_t b0_event;                     // recorded when the first gradient bucket (phase-1 nodes + heads) is complete
@@ -701,6 +702,7 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
   rt->cap_next = 0;
   rt->stamps = nullptr;
   rt->calibrating = 0;
+  rt->lane_low_priority = 1;
   memset(&rt->upd, 0, sizeof(rt->upd));
   { PackTab& tab = P->ptab; int nt = 0; for (int i = 0; i < tab.n; ++i) { tab.tile0[i] = nt; nt += ((tab.e[i].cout + 31) / 32) * ((tab.e[i].cinpad + 31) / 32); } tab.tile0[tab.n] = nt; tab.ntiles = nt; }
   rt->b0_event = nullptr; rt->b0_enabled = false; rt->open_sched = nullptr;
@@ -955,9 +957,11 @@ static void seg_pick_lanes(PlanRt* rt, hipStream_t main_s) {
   hipStream_t cand[NC];
   int nc = 0;
   // the side lanes get the LOWEST stream priority: the chain lane's workgroups are dispatched ahead of theirs (+1.4 % on the
-  // flag-synchronised step; NUNET_SIDE_PRIO=0: default priority)
-  static int side_prio = -1;
-  if (side_prio < 0) { const char* e = getenv("NUNET_SIDE_PRIO"); side_prio = e ? atoi(e) : 1; }
+  // flag-synchronised step) - unless the caller says otherwise (nunet_plan_set_lane_priority): with RCCL's high-priority stream in
+  // the process, lowest-priority lanes are served in time slices (every kernel on one of them took 100-190 us in the
+  // data-parallel rehearsal: 3.4-4.4 ms per step against 1.82 at default priority). NUNET_SIDE_PRIO overrides both.
+  int side_prio = rt->lane_low_priority;
+  { const char* e = getenv("NUNET_SIDE_PRIO"); if (e) side_prio = atoi(e); }
   int pr_least = 0, pr_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
   // (measured and not kept: side lanes on CU-masked streams - hipExtStreamCreateWithCUMask, 16 to 96 CUs kept free for the chain -
@@ -981,11 +985,27 @@ static void seg_pick_lanes(PlanRt* rt, hipStream_t main_s) {
     if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); return false; }
     return ms * 1000.f < 1.5f * SPIN_US;
   };
+  // A lane must also DISPATCH at the caller's stream's rate: with RCCL initialised in the process, some streams sit on queues that
+  // the hardware scheduler serves in time slices - every kernel on such a lane took 100-190 us in the data-parallel rehearsal
+  // (4.1 ms per step). Eight back-to-back 2 us kernels, timed on the candidate against the same on the caller's stream.
+  auto chain_us = [&](hipStream_t a) {
+    (void)hipStreamSynchronize(a);
+    (void)nunet_debug_spin(2, 1, a);
+    (void)hipEventRecord(e0, a);
+    for (int q = 0; q < 8; ++q) (void)nunet_debug_spin(2, 1, a);
+    (void)hipEventRecord(e1, a);
+    (void)hipStreamSynchronize(a);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); return 1e9f; }
+    return ms * 1000.f;
+  };
+  const float base_us = std::min(chain_us(main_s), chain_us(main_s));
   hipStream_t pick[3]; int np = 0;
   bool usedc[NC] = {false};
   for (int k = 0; k < nc && np < 3; ++k) {
     // (also clear of the process's default stream: the copies of the next batch are usually queued there)
     bool ok = overlap(main_s, cand[k]) && overlap((hipStream_t)nullptr, cand[k]);
+    if (ok) { const float c_us = std::min(chain_us(cand[k]), chain_us(cand[k])); ok = c_us < 2.5f * base_us + 20.f; }
     for (int q = 0; q < np && ok; ++q) ok = overlap(pick[q], cand[k]);
     if (ok) { pick[np++] = cand[k]; usedc[k] = true; }
   }
@@ -2051,6 +2071,12 @@ extern "C" int nunet_plan_stamps_read(nunet_plan* P, int32_t pass, uint64_t* tic
 // Calibration of the list scheduler: between begin = 1 and begin = 0 every pass runs on ONE lane with a device timestamp behind
 // every op (capture one step into a graph, replay it a few times, synchronise); begin = 0 turns the stamps into the isolated cost
 // of every op (by name: "B04.dgrad1" ...), which later passes use instead of the built-in estimates.
+extern "C" int nunet_plan_set_lane_priority(nunet_plan* P, int32_t lowest) {
+  NUNET_REQUIRE(P, "plan_set_lane_priority: null plan");
+  rt_of(P)->lane_low_priority = lowest ? 1 : 0;
+  return NUNET_OK;
+}
+
 extern "C" int nunet_plan_calibrate(nunet_plan* P, int32_t begin) {
   NUNET_REQUIRE(P, "plan_calibrate: null plan");
   PlanRt* rt = rt_of(P);

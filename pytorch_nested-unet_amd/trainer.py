@@ -103,6 +103,9 @@ class TrainStep:
         # NUNET_FORCE_DP=1: take the data-parallel code path (bucketed exchange, three graphs) with any world size, so that a
         # one-GPU box can rehearse it over RCCL with a single rank (bench.py initialises the process group)
         self.dp = self.world > 1 or (os.environ.get("NUNET_FORCE_DP") == "1" and dist.is_initialized())
+        if self.dp:
+            # RCCL's high-priority stream lives in this process: beside it lowest-priority lanes are served in time slices
+            L.check(L.lib().nunet_plan_set_lane_priority(self.pl.handle, 0), "plan_set_lane_priority")
         # Data-parallel step layout (NUNET_DP_MODE). 1 (default): one lane-faithful graph for forward + loss + the whole
         # backward, ONE exchange of the complete gradient scratch, one graph for unpack + SGD. 0: backward cut in two phases
         # so that bucket 0's exchange runs beside phase 2. Measured on one MI355X (single-rank RCCL group,
@@ -495,33 +498,42 @@ class TrainStep:
         if dist.get_backend(self.pg) != "gloo":
             # (the flag-synchronised lanes only where every rank has a device of its own: ranks sharing one GPU - the rehearsal
             #  tests - also share its hardware queues, and a polling kernel may then sit in front of the signal it waits for)
-            # Off by default: measured on one rank with RCCL initialised, the flag-synchronised pass takes 3.3 ms against 1.98 for
-            # the graph - RCCL's own streams take the process past ROCm's four hardware queues, and a lane that shares its queue
-            # with another stream serialises behind it. NUNET_DP_FLAGS=1 makes it a candidate.
-            if self.world <= torch.cuda.device_count() and os.environ.get("NUNET_DP_FLAGS", "0") == "1":
+            # (one-rank rehearsal with RCCL initialised: flag lanes 1.82 ms, graph 1.96-1.98 ms per step - with the side lanes at
+            #  DEFAULT stream priority; at the lowest priority, beside RCCL's high-priority stream, 3.4-4.4 ms. NUNET_DP_FLAGS=0
+            #  takes the candidate out.)
+            if self.world <= torch.cuda.device_count() and os.environ.get("NUNET_DP_FLAGS", "1") == "1":
                 modes.append((1, ("flags", "list")))
             modes.append((3, (False, "lanes")))
+        def all_agree(ok):
+            """A candidate is timed only if EVERY rank recorded it: the timing loop holds collectives, and a rank that skipped it
+            would leave the others waiting in them."""
+            f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.eng.device)
+            if dist.get_backend(self.pg) == "gloo":
+                h = f.cpu(); dist.all_reduce(h, op=dist.ReduceOp.MIN, group=self.pg); f = h
+            else:
+                dist.all_reduce(f, op=dist.ReduceOp.MIN, group=self.pg)
+            return bool(f.item() > 0.5)
+
         for mode, ex in modes:
             self.dp_mode = mode
             self.dp_exec = ex
-            if mode == 3:
-                try:
+            err = None
+            try:
+                if mode == 3:
                     self._capture_in_graph_exchange(s)
-                except Exception as e:           # a runtime that cannot capture the collectives: layout 1 stays (every rank runs the same code)
-                    print("[nunet] data-parallel layout 3 (exchange inside the step's graph) could not be captured: %s" % e)
-                    times.append(float("inf"))
-                    continue
-                run = self.g_fb.replay
-            else:
-                try:
+                    run = self.g_fb.replay
+                else:
                     self._capture_one_pass(s)
-                except Exception as e:
-                    if ex[0] is False:
-                        raise
-                    print("[nunet] data-parallel layout 1 on flag-synchronised lanes could not be recorded: %s" % e)
-                    times.append(float("inf"))
-                    continue
-                run = lambda: self._dp_step(self.g_fb.replay, None, self.g_opt.replay)
+                    run = lambda: self._dp_step(self.g_fb.replay, None, self.g_opt.replay)
+            except Exception as e:       # e.g. a runtime that cannot capture the collectives, no two streams on distinct queues
+                err = e
+            if not all_agree(err is None):
+                if (mode, ex) == modes[0]:
+                    raise err if err is not None else L.NunetError("data-parallel layout 1 could not be captured on another rank")
+                print("[nunet] data-parallel candidate (layout %d, %s/%s) could not be captured on every rank%s"
+                      % (mode, ex[0], ex[1], ": %s" % err if err is not None else ""))
+                times.append(float("inf"))
+                continue
             for _ in range(2):
                 run()
             torch.cuda.synchronize()
