@@ -610,9 +610,11 @@ extern "C" nunet_plan* nunet_plan_create(const nunet_plan_cfg* cfg) {
       const ConvL& o = cv ? n.c1 : n.c2;
       // (96x96 bs16, measured: 64/128, 64/256, 128/512, 256/512 are all slower in the step. 256x256 bs32: twice the workgroups are
       //  24 % faster alone - 4.34 -> 3.29 ms over the 15 launches - and +2.3 % on the step: with 7 x the pixels per slice the
-      //  slices are long enough to amortise a workgroup's start and the K-split slabs stay small beside the tensors read)
-      const int wg_mul = (long long)cfg->N * cfg->H * cfg->W >= (1LL << 20) ? 2 : 1;
-      c.wg_target = wg_mul * (c.cinpad < o.cinpad ? 128 : 256);
+      //  slices are long enough to amortise a workgroup's start and the K-split slabs stay small beside the tensors read.
+      //  Re-measured under the list-scheduled executor at 96x96 bs16: 64/128, 80/160, 96/192, 128/256, 160/320 = 9242, 9277, 9211-9357,
+      //  9146-9247, 9107 images/s: a little fewer workgroups leave the chain's kernels more room: 96/192.)
+      const bool big = (long long)cfg->N * cfg->H * cfg->W >= (1LL << 20);
+      c.wg_target = big ? (c.cinpad < o.cinpad ? 256 : 512) : (c.cinpad < o.cinpad ? 96 : 192);
       nunet_wgrad_desc wd; memset(&wd, 0, sizeof(wd));
       wd.N = cfg->N; wd.H = P->hl[n.i]; wd.W = P->wl[n.i]; wd.C0 = c.cinpad; wd.Cout = c.cout; wd.target_wgs = c.wg_target; wd.max_slabs = ks_max;
       c.ks = nunet_conv3x3_wgrad_slabs(&wd);
@@ -1119,8 +1121,13 @@ int Sched::run_list() {
   // concurrent stream costs the critical chain more than its overlap buys; limiting the summed chip share of the concurrent ops
   // instead (a capacity model over the launch grids) only lost: 1.5 / 2.0 / 2.5 / 3.0 full-chip ops at once = 6610 / 8480 / 8720 /
   // 9260. A crossing dependency costs one sync kernel on each side (XSYNC; 0 / 3 / 10 us in the model: no difference).
-  static int NL = 0; static float XSYNC = 3.f;
-  if (!NL) { const char* e = getenv("NUNET_LIST_LANES"); NL = e ? atoi(e) : 3; if (NL < 1 || NL > NLMAX) NL = 3; }
+  static int NLs[2] = {0, 0}; static float XSYNC = 3.f;
+  if (!NLs[0]) {
+    const char* e = getenv("NUNET_LIST_LANES"); NLs[0] = NLs[1] = e ? atoi(e) : 3;
+    const char* f = getenv("NUNET_LIST_LANES_FWD"); if (f) NLs[0] = atoi(f);
+    for (int q = 0; q < 2; ++q) if (NLs[q] < 1 || NLs[q] > NLMAX) NLs[q] = 3;
+  }
+  const int NL = NLs[pass & 1];
   std::vector<std::vector<int>> succ(n), pred(n);
   std::vector<int> indeg(n, 0);
   {

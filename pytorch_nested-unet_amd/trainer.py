@@ -426,9 +426,15 @@ class TrainStep:
                 torch.cuda.synchronize()
             finally:
                 L.check(L.lib().nunet_plan_calibrate(self.pl.handle, 0), "plan_calibrate")
-            del g
+            # (kept alive while the program below picks its lanes: with the calibration graph - and its launch stream - destroyed
+            #  first, 4 of 20 processes came up with a flag program at 4.8 ms per step instead of 1.7; with it alive 0 of 12, like
+            #  the capture-time choice, whose first candidate - a native graph - is alive at that point: 0 of 26. Which stream
+            #  inherits the freed hardware-queue slot decides; ROCm offers no way to ask.)
+            self._calib_graph = g
             self._calibrated = True
-        return _SegProgram(s, body, flags=segmented == "flags") if segmented else _NativeGraph(s, body)
+        prog = _SegProgram(s, body, flags=segmented == "flags") if segmented else _NativeGraph(s, body)
+        self._calib_graph = None
+        return prog
 
     def _choose_executor(self, s, body, reps=20):
         """Time the two executable forms of the captured step on this device and keep the faster: the multi-branch hipGraph
