@@ -413,6 +413,11 @@ int nunet_plan_calibrate(nunet_plan* p, int32_t begin);
  * first) or at the default priority (0: needed when another library's high-priority stream lives in the process - RCCL's -,
  * beside which lowest-priority queues are served in time slices). Set before the first recording. */
 int nunet_plan_set_lane_priority(nunet_plan* p, int32_t lowest);
+/* Forget the side lanes: the next NUNET_SEG_* recording measures and picks new streams (the old ones stay alive until the plan is
+ * destroyed, so programs recorded on them stay valid and the new candidates land on other hardware-queue slots). For a caller that
+ * times its freshly recorded program and finds it far off the single-lane step (TrainStep does: which queue a stream inherits is
+ * ROCm's choice, and unchecked 1 process in 5 came up with a program at 4.8 ms per step instead of 1.7). */
+int nunet_plan_reset_lanes(nunet_plan* p);
 int nunet_plan_set_schedule(nunet_plan* p, int32_t schedule);
 /* debug/test access to an intermediate: name like "x0_0", "x2_1" (block
  * outputs, NHWC). Returns byte offset into arena; fills pitch/channels. */

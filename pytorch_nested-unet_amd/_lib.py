@@ -161,6 +161,7 @@ _SIG = {
     "nunet_plan_set_schedule": (_i32, [_vp, _i32]),
     "nunet_plan_calibrate": (_i32, [_vp, _i32]),
     "nunet_plan_set_lane_priority": (_i32, [_vp, _i32]),
+    "nunet_plan_reset_lanes": (_i32, [_vp]),
     "nunet_plan_set_lanes": (_i32, [_vp, C.POINTER(_vp), _i32]),
     "nunet_profile_begin": (_i32, []),
     "nunet_profile_end": (_i32, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),

@@ -469,6 +469,7 @@ struct PlanRt {  // runtime objects owned by the plan (host side only)
   bool b0_enabled;
   int seg_lanes_distinct;                  // how many of them were measured to run beside the caller's stream and each other
   hipStream_t seg_lanes[3];                // side-lane streams of the segmented recording (created together: distinct hardware queues)
+  std::vector<hipStream_t> seg_owned;      // every stream seg_pick_lanes created and kept (destroyed with the plan)
   struct Sched* open_sched;                // backward pass left open after phase 1 (nunet_plan_backward_phase bit 3): lanes, dependency state
   std::vector<hipEvent_t> b0_events;       // ... and the last-writer events of the first bucket's gradients, for nunet_plan_bucket0_wait
   std::vector<std::string> stamp_labels[2];
@@ -731,11 +732,7 @@ extern "C" void nunet_plan_destroy(nunet_plan* p) {
     if (!p->rt->lanes_external)
       for (int l = 0; l < NLANES; ++l) if (p->rt->lanes[l]) (void)hipStreamDestroy(p->rt->lanes[l]);
     for (size_t k = 0; k < p->rt->cap_streams.size(); ++k) (void)hipStreamDestroy(p->rt->cap_streams[k]);
-    for (int q = 0; q < 3; ++q) {
-      bool dup = false;
-      for (int r = 0; r < q; ++r) dup |= p->rt->seg_lanes[r] == p->rt->seg_lanes[q];
-      if (p->rt->seg_lanes[q] && !dup && p->rt->seg_lanes[q] != p->rt->lanes[q + 1]) (void)hipStreamDestroy(p->rt->seg_lanes[q]);
-    }
+    for (size_t k = 0; k < p->rt->seg_owned.size(); ++k) (void)hipStreamDestroy(p->rt->seg_owned[k]);
     for (int q = 0; q < 2; ++q)
       for (size_t k = 0; k < p->rt->events[q].size(); ++k) (void)hipEventDestroy(p->rt->events[q][k]);
     if (p->rt->stamps) (void)hipFree(p->rt->stamps);
@@ -1011,7 +1008,7 @@ static void seg_pick_lanes(PlanRt* rt, hipStream_t main_s) {
     for (int q = 0; q < np && ok; ++q) ok = overlap(pick[q], cand[k]);
     if (ok) { pick[np++] = cand[k]; usedc[k] = true; }
   }
-  for (int k = 0; k < nc; ++k) if (!usedc[k]) (void)hipStreamDestroy(cand[k]);
+  for (int k = 0; k < nc; ++k) { if (!usedc[k]) (void)hipStreamDestroy(cand[k]); else rt->seg_owned.push_back(cand[k]); }
   // (fewer than three distinct queues found: lanes share a STREAM - never two streams of one queue, which the flag-synchronised
   //  program could not survive: a polling kernel ahead of its signal in the same queue)
   for (int q = 0; q < 3; ++q) rt->seg_lanes[q] = q < np ? pick[q] : (np > 0 ? pick[q % np] : main_s);
@@ -1144,6 +1141,11 @@ int Sched::run_list() {
   }
   std::vector<float> prio(n, 0.f), tend(n, 0.f);
   for (int i = n - 1; i >= 0; --i) { float m = 0.f; for (int s : succ[i]) m = std::max(m, prio[s]); prio[i] = ops[i].cost + m; }
+  {
+    static float leaf_bias = -1e30f;
+    if (leaf_bias < -1e29f) { const char* e = getenv("NUNET_LIST_LEAF_BIAS"); leaf_bias = e ? (float)atof(e) : 0.f; }
+    if (leaf_bias != 0.f) for (int i = 0; i < n; ++i) if (ops[i].leaf) prio[i] += leaf_bias;
+  }
   std::vector<int> ready, lane(n, 0), order;
   float lane_free[NLMAX] = {0.f, 0.f, 0.f, 0.f};
   for (int i = 0; i < n; ++i) if (indeg[i] == 0) ready.push_back(i);
@@ -2078,6 +2080,19 @@ extern "C" int nunet_plan_stamps_read(nunet_plan* P, int32_t pass, uint64_t* tic
 // Calibration of the list scheduler: between begin = 1 and begin = 0 every pass runs on ONE lane with a device timestamp behind
 // every op (capture one step into a graph, replay it a few times, synchronise); begin = 0 turns the stamps into the isolated cost
 // of every op (by name: "B04.dgrad1" ...), which later passes use instead of the built-in estimates.
+// Forget the side lanes of the flag-synchronised program: the next recording measures and picks new ones (the old streams stay
+// alive - and keep their hardware-queue slots - until the plan is destroyed, so the new candidates land elsewhere). For a caller
+// that finds its program slow: which queue a stream inherits is ROCm's choice, and 1 process in 5 came up with a program at
+// 4.8 ms per step instead of 1.7 when nothing checked. No program recorded on the old lanes may be replayed afterwards... it may:
+// the streams live on; it just keeps its lanes.
+extern "C" int nunet_plan_reset_lanes(nunet_plan* P) {
+  NUNET_REQUIRE(P, "plan_reset_lanes: null plan");
+  PlanRt* rt = rt_of(P);
+  rt->seg_lanes[0] = rt->seg_lanes[1] = rt->seg_lanes[2] = nullptr;
+  rt->seg_lanes_distinct = 0;
+  return NUNET_OK;
+}
+
 extern "C" int nunet_plan_set_lane_priority(nunet_plan* P, int32_t lowest) {
   NUNET_REQUIRE(P, "plan_set_lane_priority: null plan");
   rt_of(P)->lane_low_priority = lowest ? 1 : 0;

@@ -424,6 +424,7 @@ class TrainStep:
                     for _ in range(3):
                         g.replay()
                 torch.cuda.synchronize()
+                self._single_lane_ms = self._time_program(g, 5)     # (with the stamp kernels: an upper bound of the one-lane step)
             finally:
                 L.check(L.lib().nunet_plan_calibrate(self.pl.handle, 0), "plan_calibrate")
             # (kept alive while the program below picks its lanes: with the calibration graph - and its launch stream - destroyed
@@ -432,9 +433,43 @@ class TrainStep:
             #  inherits the freed hardware-queue slot decides; ROCm offers no way to ask.)
             self._calib_graph = g
             self._calibrated = True
-        prog = _SegProgram(s, body, flags=segmented == "flags") if segmented else _NativeGraph(s, body)
+        if segmented == "flags" and getattr(self, "_single_lane_ms", None):
+            # A flag program is checked against the one-lane step before it is used: which hardware queue a lane inherits is
+            # ROCm's choice, and unchecked 1 process in 5 came up at 4.8 ms per step instead of 1.7 (every lane's kernels
+            # serialised). Such a program is thrown away and recorded again on newly picked lanes.
+            prog = None
+            for attempt in range(3):
+                prog = _SegProgram(s, body, flags=True)
+                ms = self._time_program(prog, 8)
+                if ms < 0.9 * self._single_lane_ms:
+                    break
+                print("[nunet] flag-synchronised program came up at %.2f ms per step (one lane: %.2f): picking new lanes (%d)"
+                      % (ms, self._single_lane_ms, attempt + 1))
+                if attempt < 2:
+                    prog = None
+                    L.check(L.lib().nunet_plan_reset_lanes(self.pl.handle), "plan_reset_lanes")
+        else:
+            prog = _SegProgram(s, body, flags=segmented == "flags") if segmented else _NativeGraph(s, body)
         self._calib_graph = None
         return prog
+
+    def _time_program(self, g, reps):
+        """ms per replay of a recorded program, issued the way step() issues it (batch copy + replay from the caller's stream)."""
+        buf = self.x_u8 if self.input_u8 else self.x
+        fresh = buf.clone()
+        def one():
+            buf.copy_(fresh, non_blocking=True)
+            g.replay()
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
 
     def _choose_executor(self, s, body, reps=20):
         """Time the two executable forms of the captured step on this device and keep the faster: the multi-branch hipGraph
