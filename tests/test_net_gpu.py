@@ -776,6 +776,50 @@ def test_segmented_step_program_equals_the_single_graph(synth):
             assert torch.equal(a, b)
 
 
+def test_flag_program_survives_a_lane_reset_and_the_capture_time_choice_is_recorded(synth):
+    """nunet_plan_reset_lanes: the next recording picks new side-lane streams (the old ones stay alive, a program recorded on them
+    stays valid); a program recorded after the reset computes the same bits. And the default TrainStep (no executor pinned) times
+    both executors at capture and says which it kept."""
+    from nunet_amd.trainer import TrainStep, _SegProgram
+    n, hw = 16, 96
+    torch.manual_seed(13)
+    sd = {k: v.clone() for k, v in nunet_amd.archs.NestedUNet(1, 3, False).state_dict().items()}
+    batches = [synth.synth_batch(n, hw, hw, 3, 1, seed=340 + k) for k in range(2)]
+
+    def run(ts):
+        for img, msk in batches:
+            ts.step(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV))
+        torch.cuda.synchronize()
+        return [t.clone() for t in (ts.eng.flat_params, ts.mom, ts.eng.bnbuf, ts.loss_out)]
+
+    outs = []
+    for reset in (False, True):
+        m = nunet_amd.archs.NestedUNet(1, 3, False, dtype="bf16")
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2, segmented="flags", schedule="list")
+        x0, t0 = torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV)
+        ts.capture(x0, t0)
+        if reset:
+            old = ts.g_fb
+            L.check(L.lib().nunet_plan_reset_lanes(ts.pl.handle), "plan_reset_lanes")
+            ts.capture(x0, t0)                     # a second recording: new lanes
+            assert isinstance(ts.g_fb, _SegProgram) and ts.g_fb is not old
+        outs.append(run(ts))
+        del ts, m
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    m = nunet_amd.archs.NestedUNet(1, 3, False, dtype="bf16")
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    ts = TrainStep(m, (n, 3, hw, hw), lr=1e-2)
+    ts.capture(torch.from_numpy(batches[0][0]).to(DEV), torch.from_numpy(batches[0][1]).to(DEV))
+    assert ts.executor_choice and set(ts.executor_choice) == {(False, "lanes"), ("flags", "list")}
+    assert (ts.segmented, ts.schedule) == min(ts.executor_choice, key=ts.executor_choice.get)
+    for a, b in zip(outs[0], run(ts)):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_single_stream_schedule_with_grouped_convs_equals_the_lane_schedule(dtype, synth):
     """TrainStep(schedule='wave') / nunet_plan_set_schedule: the pass emitted on ONE stream in dependency order by a critical-path list scheduler, every ready 3x3
