@@ -457,7 +457,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_kernel(ConvGroup grp)
   auto sweep = [&](auto LOADS, const LoadCtx& lc) {
     constexpr bool WITH_LOADS = decltype(LOADS)::value;
     // Fragment reads run PD steps ahead of the MFMAs that consume them (PD + 1 register buffers). Measured: 2 or 3
-    // steps ahead cost 12-30 registers and change no layer's time (tools/conv_layers.py), so one step it is.
+    // steps ahead cost 12-30 registers and change no layer's time (tools/conv_layers.py), so one step it is. (Round 3, again and
+    // together with a second accumulator chain for the one-tile-per-wave configuration - two independent MFMA chains per wave -:
+    // 1192 us over the 59 launches either way; the second chain alone costs the BatchNorm-loader kernels 14 %: its fold and
+    // registers. Neither the fragment-read latency nor the MFMA dependency is what a sweep waits for.)
     constexpr int PD = 1;
     constexpr int NB = PD + 1;
     typename M::Frag fa[NB][SM], fb[NB][SN];
