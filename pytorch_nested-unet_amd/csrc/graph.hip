@@ -234,11 +234,11 @@ constexpr unsigned long long LANE_WAIT_TIMEOUT_TICKS = 400000000ull;   // s_memr
 constexpr int LANE_SYNC_MAX = 12;          // signals / waits per sync kernel (more: a second kernel)
 struct LaneSyncP { unsigned* flags; unsigned* ctr; unsigned* err; unsigned* derr; int bump, nsig, nwait; unsigned short sig[LANE_SYNC_MAX], wait[LANE_SYNC_MAX]; };
 __global__ __launch_bounds__(64) void lane_sync_kernel(LaneSyncP p) {
-  __shared__ unsigned s_step;
+  // (one wave: lane 0 reads - and, in the lane's first sync kernel, bumps - the replay counter, readfirstlane hands it round)
   const int t = threadIdx.x;
-  if (t == 0) { unsigned v = *p.ctr; if (p.bump) { ++v; *p.ctr = v; } s_step = v; }
-  __syncthreads();
-  const unsigned step = s_step;
+  unsigned v = 0u;
+  if (t == 0) { v = *p.ctr; if (p.bump) { ++v; *p.ctr = v; } }
+  const unsigned step = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
   if (t < p.nsig) __hip_atomic_store(p.flags + p.sig[t], step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (t >= 32 && t - 32 < p.nwait) {
     const unsigned* flag = p.flags + p.wait[t - 32];
