@@ -1055,7 +1055,10 @@ static int conv_cfg_of(const nunet_conv_desc* d) {
   // (256x256 bs32, tools/conv_layers.py with nunet_conv_desc.tile: with >= 1M pixels the 256-pixel tile wins for every Cout = 32
   //  layer - 8 or more items per resident workgroup, no round quantisation left, the weight stage shared by twice the pixels:
   //  level-0 conv1 -13 %, conv2 -3 %)
-  const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD && px < (1L << 20));
+  //  (re-measured after the XCD remap, 96x96 bs16: the plain / BN-forward Cout = 64 convs of level 1 - 36864 pixels - are 8 % faster
+  //   on the small tile as well: conv1 21.5 -> 19.7, conv2 14.1 -> 12.8 us; their input-gradient convs are not: 20.7 -> 32.6)
+  const bool small = items_std < 256 || (cout == 32 && d->in_tf != NUNET_TF_BN_RELU_BWD && px < (1L << 20)) ||
+                     (cout == 64 && d->in_tf != NUNET_TF_BN_RELU_BWD && px < (1L << 16));
   if (small) return 0;
   return cout % 64 == 0 ? 1 : 2;
 }
